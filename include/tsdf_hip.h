@@ -1,0 +1,189 @@
+/*
+ * tsdf_hip.h -- C ABI of libtsdf_hip.so, the MI355X (gfx950) TSDF volumetric-fusion library.
+ *
+ * This is the drop-in boundary for the dense-grid TSDF path of Tariq-Abuhashim/semantic-slam.
+ * Every entry point below replaces one piece of the reference's `class TSDF`
+ * (include/tsdf.hpp:22-98, src/tsdf.cu) and is what a binding on the reference side would
+ * call (include/tsdf.hpp and include/TSDFfusion.hpp in this repository
+ * are those bindings for C++).  Citations "ref:" are paths inside the reference repository.
+ *
+ * Conventions
+ *   - plain C: opaque handle, pointers and sizes only; no C++/torch types cross the boundary
+ *   - every function returns TSDF_OK (0) or a negative tsdf_status; the message of the last
+ *     failure on the calling thread is tsdf_last_error()
+ *   - matrices are 16 floats, row-major 4x4 (ref: src/tsdf.cu:253); intrinsics are 9 floats,
+ *     row-major 3x3 (ref: include/tsdf.hpp:96)
+ *   - grids are x-fastest: index = (z*dim_y + y)*dim_x + x (ref: src/tsdf.cu:52)
+ *   - a handle owns one z-slab [z_begin, z_end) of the global grid on one device and one
+ *     HIP stream; distinct handles may be driven from distinct threads, one handle may not
+ *     (ref: the reference holds one TSDF per Object and never shares it, src/Engine.cpp:170-172)
+ *   - "host" pointers are ordinary memory the caller owns and may free as soon as the call
+ *     returns; "device" pointers are HBM addresses valid on the handle's device
+ */
+#ifndef TSDF_HIP_H
+#define TSDF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tsdf_volume tsdf_volume; /* opaque */
+
+typedef enum tsdf_status {
+    TSDF_OK = 0,
+    TSDF_ERR_INVALID = -1,   /* bad argument (NULL, non-positive size, slab outside the grid) */
+    TSDF_ERR_HIP = -2,       /* a HIP runtime call failed; tsdf_last_error() has its name */
+    TSDF_ERR_IO = -3,        /* file could not be written / read */
+    TSDF_ERR_NO_DEVICE = -4  /* no usable gfx950 device */
+} tsdf_status;
+
+/*
+ * Everything that is a compile-time member initialiser in the reference, made run-time.
+ * tsdf_config_default() fills in exactly the reference's values:
+ *   dims 200^3, voxel 0.004 m, trunc 5*voxel   (ref: include/tsdf.hpp:63-67)
+ *   K = TUM fr3 {535.4,0,320.1, 0,539.2,247.6, 0,0,1} (ref: include/tsdf.hpp:96)
+ *   max_depth 6 m                               (ref: src/tsdf.cu:46)
+ *   base2world = identity, origin = 0, slab = whole grid, device 0
+ */
+typedef struct tsdf_config {
+    int32_t im_height, im_width;       /* depth image size (ref ctor args h, w: src/tsdf.cu:62) */
+    int32_t dim_x, dim_y, dim_z;       /* GLOBAL grid size in voxels */
+    int32_t z_begin, z_end;            /* this handle's slab, global z in [z_begin, z_end) */
+    float voxel_size;                  /* metres */
+    float trunc_margin;                /* metres */
+    float max_depth;                   /* depth samples > max_depth are ignored */
+    float origin[3];                   /* grid origin in the base camera frame (ref ctor arg) */
+    float cam_K[9];                    /* intrinsics */
+    float base2world[16];              /* base camera pose (ref ctor arg base2world_vec) */
+    int32_t device;                    /* HIP device ordinal */
+    int32_t id;                        /* names tsdf<id>.ply / tsdf<id>.bin (ref: src/tsdf.cu:109,116) */
+} tsdf_config;
+
+/* Fill *cfg with the reference defaults for an h x w depth image. */
+int tsdf_config_default(tsdf_config *cfg, int32_t im_height, int32_t im_width);
+
+/*
+ * Replaces TSDF::TSDF (ref: src/tsdf.cu:62-96): allocates the slab in HBM, sets TSDF = 1 and
+ * weight = 0 on the device (no host fill + upload), inverts base2world (a singular
+ * base2world leaves the inverse all-zero and is not an error, as in ref: src/tsdf.cu:74).
+ */
+int tsdf_create(const tsdf_config *cfg, tsdf_volume **out);
+
+/* Frees device memory, the stream and staging buffers.  Writes no files (see tsdf_save_*). */
+int tsdf_destroy(tsdf_volume *vol);
+
+/* Back to TSDF = 1, weight = 0 (ref: src/tsdf.cu:79-81), asynchronously on the handle's stream. */
+int tsdf_reset(tsdf_volume *vol);
+
+/*
+ * Replaces TSDF::Integrate (ref: src/tsdf.cu:135-168).  depth_host: im_height*im_width floats,
+ * metres, row-major, borrowed for the call only (copied to a pinned staging slot before
+ * returning).  cam2world: current camera pose.  cam2base = inverse(base2world) * cam2world
+ * is composed on the host in the reference's fp32 operation order (ref: src/tsdf.cu:142).
+ * The kernel is queued on the handle's stream; the call does not wait for it.
+ */
+int tsdf_integrate(tsdf_volume *vol, const float *depth_host, const float cam2world[16]);
+
+/* Same, with the depth frame already resident in HBM on the handle's device (no copy). */
+int tsdf_integrate_device(tsdf_volume *vol, const float *depth_dev, const float cam2world[16]);
+
+/*
+ * Same as tsdf_integrate_device, for callers that composed the relative pose themselves
+ * (cam2base is used as given; base2world is ignored).
+ */
+int tsdf_integrate_cam2base(tsdf_volume *vol, const float *depth_dev, const float cam2base[16]);
+
+/*
+ * Per-instance fusion as the reference's caller prepares it: depth * (mask/255) with an
+ * 8-bit {0,255} instance mask (ref: src/Engine.cpp:192-193), fused into the depth load
+ * instead of materialising the masked image.  mask_dev: im_height*im_width bytes in HBM.
+ */
+int tsdf_integrate_masked_device(tsdf_volume *vol, const float *depth_dev, const uint8_t *mask_dev,
+                                 const float cam2world[16]);
+
+/* Block until everything queued on the handle's stream has finished. */
+int tsdf_sync(tsdf_volume *vol);
+
+/*
+ * Copy this handle's slab to host arrays of tsdf_slab_voxels() floats each (either may be
+ * NULL).  The reference only ever reads results back in its destructor
+ * (ref: src/tsdf.cu:101-104); this is the same copy, callable at any time.  Synchronous.
+ */
+int tsdf_download(tsdf_volume *vol, float *tsdf_host, float *weight_host);
+
+/* Restore a slab from host arrays (resume from a saved state).  Synchronous. */
+int tsdf_upload(tsdf_volume *vol, const float *tsdf_host, const float *weight_host);
+
+/* Device addresses of the slab's two arrays (x-fastest, slab-local z). */
+int tsdf_device_ptrs(tsdf_volume *vol, float **tsdf_dev, float **weight_dev);
+
+/* Number of voxels in this handle's slab: dim_x * dim_y * (z_end - z_begin). */
+int64_t tsdf_slab_voxels(const tsdf_volume *vol);
+
+/* Copy of the configuration the handle was created with. */
+int tsdf_get_config(const tsdf_volume *vol, tsdf_config *out);
+
+/* The relative pose used by the most recent integrate call (16 floats), for parity tests. */
+int tsdf_last_cam2base(const tsdf_volume *vol, float out[16]);
+
+/*
+ * Run subsequent work of this handle on a caller-owned hipStream_t (passed as void*), e.g.
+ * the current PyTorch stream, or back on the handle's own stream when stream == NULL.
+ */
+int tsdf_set_stream(tsdf_volume *vol, void *hip_stream);
+int tsdf_get_stream(tsdf_volume *vol, void **hip_stream);
+
+/*
+ * Number of voxels whose weight is > weight_thresh and whose TSDF is non-zero: the surface
+ * test of ref: src/tsdf.cu:179, counted on the device.  Synchronous.
+ */
+int tsdf_count_surface(tsdf_volume *vol, float weight_thresh, int64_t *count);
+
+/*
+ * Surface points of the slab in grid order, xyz triples in the base camera frame
+ * (ref: src/tsdf.cu:195-212), compacted on the device.  xyz_host receives at most
+ * capacity points; *count is the number found.  Synchronous.
+ */
+int tsdf_extract_surface(tsdf_volume *vol, float weight_thresh, float *xyz_host, int64_t capacity,
+                         int64_t *count);
+
+/*
+ * File writers, byte-compatible with the reference's destructor (ref: src/tsdf.cu:107-132,
+ * 170-218).  For a slab handle the .bin header carries the slab's dims and a z-shifted
+ * origin is NOT applied: callers that shard gather slabs in z order first (see
+ * semantic_slam_amd/sharded.py); a whole-grid handle writes exactly the reference's files.
+ *   .ply: binary_little_endian points with |tsdf| != 0 and weight > weight_thresh (0.9 in the ref)
+ *   .bin: 8-float header {dim_x, dim_y, dim_z, origin xyz, voxel_size, trunc} + TSDF floats
+ */
+int tsdf_save_ply(tsdf_volume *vol, const char *path, float weight_thresh);
+int tsdf_save_bin(tsdf_volume *vol, const char *path);
+
+/*
+ * Timing aid for benchmarks: queue n_frames integrations of one device-resident depth frame
+ * with poses cam2world[k*16..] back to back on the handle's stream, bracketed by HIP events
+ * on that stream; *elapsed_ms is the device time between the events.  Synchronous.
+ */
+int tsdf_integrate_sequence_timed(tsdf_volume *vol, const float *depth_dev, const float *cam2world,
+                                  int32_t n_frames, float *elapsed_ms);
+
+/* Select the Integrate kernel variant (0 = default; others are listed in DESIGN.md). */
+int tsdf_set_kernel_variant(tsdf_volume *vol, int32_t variant);
+
+/* Message describing the last failure on this thread ("" when none). */
+const char *tsdf_last_error(void);
+
+/* Library version string and the offload architecture it was built for ("gfx950"). */
+const char *tsdf_version(void);
+
+/* Host-side 4x4 helpers in the reference's exact fp32 operation order
+ * (ref: src/tsdf.cu:253-273 and :276-403); exported so bindings can reuse them. */
+void tsdf_multiply_matrix(const float a[16], const float b[16], float out[16]);
+int tsdf_invert_matrix(const float m[16], float inv_out[16]); /* 1 = ok, 0 = singular */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSDF_HIP_H */

@@ -1,0 +1,178 @@
+"""ctypes loader for the CPU checker (oracle/liboracle.so, oracle/_ref/libtsdf_ref.so).
+
+TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Importers allowed: tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg.  Nothing under semantic_slam_amd/ imports this module.
+
+`Oracle` wraps this project's CPU restatement (tsdf_oracle.c; each C function cites the
+reference lines it follows).  `Ref` wraps the reference's own kernel body compiled for the
+host from /root/reference/src/tsdf.cu:15-60 (`make -C oracle ref`), when that build exists.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+
+
+def build(ref=True):
+    """Compile the checker.  The reference body is only buildable where /root/reference exists."""
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+    if ref and os.path.isfile("/root/reference/src/tsdf.cu"):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Oracle:
+    """CPU restatement (kind "port" in bench.py's cpu_baseline)."""
+
+    def __init__(self):
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.isfile(path):
+            build(ref=False)
+        L = self.lib = C.CDLL(path)
+        L.oracle_integrate.restype = C.c_int64
+        L.oracle_integrate.argtypes = [_f32p, _f32p, _f32p, C.c_int, C.c_int,
+                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                       C.c_float, _f32p, _f32p, C.c_int]
+        L.oracle_init_grid.argtypes = [_f32p, _f32p, C.c_int64]
+        L.oracle_multiply_matrix.argtypes = [_f32p, _f32p, _f32p]
+        L.oracle_invert_matrix.restype = C.c_int
+        L.oracle_invert_matrix.argtypes = [_f32p, _f32p]
+        L.oracle_cam2base.argtypes = [_f32p, _f32p, _f32p]
+        L.oracle_surface_points.restype = C.c_int64
+        L.oracle_surface_points.argtypes = [_f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_float,
+                                            C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                            C.c_void_p]
+        L.oracle_save_ply.restype = C.c_int
+        L.oracle_save_ply.argtypes = [C.c_char_p, _f32p, _f32p, C.c_int, C.c_int, C.c_int,
+                                      C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                      C.c_float]
+        L.oracle_save_bin.restype = C.c_int
+        L.oracle_save_bin.argtypes = [C.c_char_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_float,
+                                      C.c_float, C.c_float, C.c_float, C.c_float]
+        L.oracle_object_origin.argtypes = [_f32p, C.c_int, C.c_int, _f32p, _f32p]
+        L.oracle_depth_prep.argtypes = [np.ctypeslib.ndpointer(dtype=np.uint16, flags="C_CONTIGUOUS"),
+                                        C.c_int, C.c_int, C.c_float, _f32p]
+        L.oracle_mask_depth.argtypes = [_f32p, np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS"),
+                                        C.c_int, _f32p]
+        L.oracle_max_threads.restype = C.c_int
+
+    # --- grid ---------------------------------------------------------------------------
+    def init_grid(self, dims, z_begin=0, z_end=None):
+        dx, dy, dz = dims
+        z_end = dz if z_end is None else z_end
+        n = dx * dy * (z_end - z_begin)
+        t = np.empty(n, np.float32)
+        w = np.empty(n, np.float32)
+        self.lib.oracle_init_grid(t, w, n)
+        return t, w
+
+    def integrate(self, K, cam2base, depth, dims, origin, voxel_size, trunc, tsdf, weight,
+                  z_begin=0, z_end=None, max_depth=6.0, threads=0):
+        """In-place update of tsdf/weight (slab-local arrays).  Returns voxels updated."""
+        dx, dy, dz = dims
+        z_end = dz if z_end is None else z_end
+        h, w = depth.shape
+        assert tsdf.size == dx * dy * (z_end - z_begin) == weight.size
+        return int(self.lib.oracle_integrate(_f32(K).ravel(), _f32(cam2base).ravel(), _f32(depth),
+                                             h, w, dx, dy, dz, z_begin, z_end,
+                                             origin[0], origin[1], origin[2], voxel_size, trunc,
+                                             max_depth, tsdf, weight, threads))
+
+    # --- pose math ----------------------------------------------------------------------
+    def multiply(self, a, b):
+        out = np.empty(16, np.float32)
+        self.lib.oracle_multiply_matrix(_f32(a).ravel(), _f32(b).ravel(), out)
+        return out
+
+    def invert(self, m):
+        out = np.zeros(16, np.float32)
+        ok = self.lib.oracle_invert_matrix(_f32(m).ravel(), out)
+        return bool(ok), out
+
+    def cam2base(self, base2world, cam2world):
+        out = np.empty(16, np.float32)
+        self.lib.oracle_cam2base(_f32(base2world).ravel(), _f32(cam2world).ravel(), out)
+        return out
+
+    # --- outputs ------------------------------------------------------------------------
+    def surface_points(self, tsdf, weight, dims, voxel_size, origin, weight_thresh=0.9):
+        dx, dy, dz = dims
+        args = (tsdf, weight, dx, dy, dz, voxel_size, origin[0], origin[1], origin[2], 1.2,
+                weight_thresh)
+        n = self.lib.oracle_surface_points(*args, None)
+        xyz = np.empty((n, 3), np.float32)
+        self.lib.oracle_surface_points(*args, xyz.ctypes.data)
+        return xyz
+
+    def save_ply(self, path, tsdf, weight, dims, voxel_size, origin, weight_thresh=0.9):
+        dx, dy, dz = dims
+        rc = self.lib.oracle_save_ply(os.fsencode(path), tsdf, weight, dx, dy, dz, voxel_size,
+                                      origin[0], origin[1], origin[2], 1.2, weight_thresh)
+        assert rc == 0
+
+    def save_bin(self, path, tsdf, dims, origin, voxel_size, trunc):
+        dx, dy, dz = dims
+        rc = self.lib.oracle_save_bin(os.fsencode(path), tsdf, dx, dy, dz, origin[0], origin[1],
+                                      origin[2], voxel_size, trunc)
+        assert rc == 0
+
+    # --- caller-side adapters -----------------------------------------------------------
+    def object_origin(self, depth, K):
+        out = np.empty(3, np.float32)
+        h, w = depth.shape
+        self.lib.oracle_object_origin(_f32(depth), h, w, _f32(K).ravel(), out)
+        return out
+
+    def depth_prep(self, raw_u16, factor=5000.0):
+        raw = np.ascontiguousarray(raw_u16, dtype=np.uint16)
+        out = np.empty(raw.shape, np.float32)
+        self.lib.oracle_depth_prep(raw, raw.shape[0], raw.shape[1], factor, out)
+        return out
+
+    def mask_depth(self, depth, mask_u8):
+        d = _f32(depth)
+        out = np.empty_like(d)
+        self.lib.oracle_mask_depth(d, np.ascontiguousarray(mask_u8, dtype=np.uint8), d.size, out)
+        return out
+
+    def max_threads(self):
+        return int(self.lib.oracle_max_threads())
+
+
+class Ref:
+    """The reference's own GpuIntegrate body on the host (kind "reference").
+
+    Whole-grid only (the reference has no slabs) and max depth fixed at 6 m (tsdf.cu:46).
+    """
+
+    path = os.path.join(_HERE, "_ref", "libtsdf_ref.so")
+
+    @classmethod
+    def available(cls):
+        return os.path.isfile(cls.path)
+
+    def __init__(self):
+        L = self.lib = C.CDLL(self.path)
+        L.ref_integrate.argtypes = [_f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                    _f32p, _f32p, C.c_int]
+        L.ref_max_threads.restype = C.c_int
+
+    def integrate(self, K, cam2base, depth, dims, origin, voxel_size, trunc, tsdf, weight, threads=0):
+        dx, dy, dz = dims
+        h, w = depth.shape
+        assert tsdf.size == dx * dy * dz == weight.size
+        self.lib.ref_integrate(_f32(K).ravel(), _f32(cam2base).ravel(), _f32(depth), h, w,
+                               dx, dy, dz, origin[0], origin[1], origin[2], voxel_size, trunc,
+                               tsdf, weight, threads)
+
+    def max_threads(self):
+        return int(self.lib.ref_max_threads())

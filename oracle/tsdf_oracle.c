@@ -1,0 +1,300 @@
+/*
+ * tsdf_oracle.c -- CPU restatement of the reference's dense-grid TSDF path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it; the shipped library (libtsdf_hip.so) never
+ * links, loads or calls anything in oracle/.
+ *
+ * Every function restates, in this project's own words, one function of
+ * /root/reference (Tariq-Abuhashim/semantic-slam) and cites the lines it follows.
+ * Arithmetic is IEEE fp32 in the reference's operation order; build with
+ * -ffp-contract=off (see oracle/Makefile) so no multiply-add is fused.
+ *
+ * Pinning: the reference has no tests or golden vectors for this path.
+ * The voxel update is pinned bit-for-bit against the reference's own kernel body
+ * (src/tsdf.cu:15-60) compiled for the host from where it lies (oracle/_ref, built by
+ * `make -C oracle ref` in the build container; tests/test_oracle_vs_ref.py) and against the
+ * fixtures under tests/golden/ that were generated from that build
+ * (tests/golden/make_golden.py).  The 4x4 helpers and the file writers are member
+ * functions of a class whose header needs OpenCV + CUDA, so they cannot be built here:
+ * they are pinned by known-answer tests only (tests/test_pose_math.py).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------
+ * Voxel update.  Follows GpuIntegrate, src/tsdf.cu:15-60.
+ *
+ * One call visits global z in [z_begin, z_end) of a dim_x*dim_y*dim_z grid (the
+ * reference launches one block per z and one thread per y, each looping over x,
+ * tsdf.cu:21-23,165); tsdf/weight point at the first voxel of slice z_begin, so a
+ * z-slab owner passes its slab-local arrays.  max_depth is the literal 6 of tsdf.cu:46.
+ * Returns the number of voxels whose weight changed.
+ * ---------------------------------------------------------------------------------- */
+int64_t oracle_integrate(const float *cam_K, const float *cam2base, const float *depth_im,
+                         int im_height, int im_width,
+                         int dim_x, int dim_y, int dim_z, int z_begin, int z_end,
+                         float origin_x, float origin_y, float origin_z,
+                         float voxel_size, float trunc_margin, float max_depth,
+                         float *tsdf, float *weight, int n_threads)
+{
+    int64_t n_updated = 0;
+    (void)dim_z;
+#ifdef _OPENMP
+    if (n_threads <= 0) n_threads = omp_get_max_threads();
+#pragma omp parallel for schedule(static) num_threads(n_threads) reduction(+ : n_updated)
+#else
+    (void)n_threads;
+#endif
+    for (int gz = z_begin; gz < z_end; ++gz) {
+        for (int gy = 0; gy < dim_y; ++gy) {
+            float *row_t = tsdf + ((int64_t)(gz - z_begin) * dim_y + gy) * dim_x;
+            float *row_w = weight + ((int64_t)(gz - z_begin) * dim_y + gy) * dim_x;
+            for (int gx = 0; gx < dim_x; ++gx) {
+                /* voxel centre in the base camera frame: origin + index*size, tsdf.cu:27-29 */
+                float bx = origin_x + (float)gx * voxel_size;
+                float by = origin_y + (float)gy * voxel_size;
+                float bz = origin_z + (float)gz * voxel_size;
+
+                /* base frame -> current camera frame: subtract the translation column,
+                 * then multiply by the transposed rotation, tsdf.cu:33-38 */
+                float dx = bx - cam2base[3];
+                float dy = by - cam2base[7];
+                float dz = bz - cam2base[11];
+                float cx = cam2base[0] * dx + cam2base[4] * dy + cam2base[8] * dz;
+                float cy = cam2base[1] * dx + cam2base[5] * dy + cam2base[9] * dz;
+                float cz = cam2base[2] * dx + cam2base[6] * dy + cam2base[10] * dz;
+                if (cz <= 0.0f) continue; /* tsdf.cu:39 */
+
+                /* pinhole projection, round half away from zero, tsdf.cu:41-42.
+                 * The reference converts the rounded float to int before the bounds
+                 * test; comparing the rounded float instead is the same test for every
+                 * value an int can hold and stays defined for those it cannot
+                 * (SURVEY.md section 8c caveat 2). */
+                float pu = roundf(cam_K[0] * (cx / cz) + cam_K[2]);
+                float pv = roundf(cam_K[4] * (cy / cz) + cam_K[5]);
+                if (!(pu >= 0.0f && pu < (float)im_width && pv >= 0.0f && pv < (float)im_height))
+                    continue; /* tsdf.cu:43 */
+                int iu = (int)pu, iv = (int)pv;
+
+                float d = depth_im[iv * im_width + iu]; /* tsdf.cu:45 */
+                if (d <= 0.0f || d > max_depth) continue; /* tsdf.cu:46 */
+
+                float diff = d - cz; /* tsdf.cu:48 */
+                if (diff <= -trunc_margin) continue; /* tsdf.cu:49 */
+
+                /* running weighted mean with observation weight 1, tsdf.cu:53-57 */
+                float dist = fminf(1.0f, diff / trunc_margin);
+                float w_old = row_w[gx];
+                float w_new = w_old + 1.0f;
+                row_w[gx] = w_new;
+                row_t[gx] = (row_t[gx] * w_old + dist) / w_new;
+                ++n_updated;
+            }
+        }
+    }
+    return n_updated;
+}
+
+/* Initial grid state: TSDF = 1, weight = 0.  Follows TSDF::TSDF, src/tsdf.cu:79-81. */
+void oracle_init_grid(float *tsdf, float *weight, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) tsdf[i] = 1.0f;
+    memset(weight, 0, sizeof(float) * (size_t)n);
+}
+
+/* ------------------------------------------------------------------------------------
+ * 4x4 row-major product.  Follows TSDF::multiply_matrix, src/tsdf.cu:253-273:
+ * each entry is a*b + a*b + a*b + a*b, summed left to right in fp32.
+ * ---------------------------------------------------------------------------------- */
+void oracle_multiply_matrix(const float *a, const float *b, float *out)
+{
+    float tmp[16];
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) {
+            float s = a[4 * r + 0] * b[0 + c];
+            s = s + a[4 * r + 1] * b[4 + c];
+            s = s + a[4 * r + 2] * b[8 + c];
+            s = s + a[4 * r + 3] * b[12 + c];
+            tmp[4 * r + c] = s;
+        }
+    memcpy(out, tmp, sizeof tmp);
+}
+
+/* ------------------------------------------------------------------------------------
+ * 4x4 row-major inverse by cofactors.  Follows TSDF::invert_matrix, src/tsdf.cu:276-403.
+ * Each cofactor is six triple products combined left to right with the signs of the
+ * reference (a leading minus negates the first factor, which is exact); the determinant
+ * is m0*c0 + m1*c4 + m2*c8 + m3*c12 (tsdf.cu:392); its reciprocal is taken in double and
+ * stored to float (tsdf.cu:397).  Returns 0 when det == 0 (tsdf.cu:394-395), 1 otherwise.
+ * ---------------------------------------------------------------------------------- */
+#define T3(a, b, c) (m[a] * m[b] * m[c])
+int oracle_invert_matrix(const float *m, float *inv_out)
+{
+    float c[16];
+    c[0]  =  T3(5, 10, 15) - T3(5, 11, 14) - T3(9, 6, 15) + T3(9, 7, 14) + T3(13, 6, 11) - T3(13, 7, 10);
+    c[4]  = -m[4] * m[10] * m[15] + T3(4, 11, 14) + T3(8, 6, 15) - T3(8, 7, 14) - T3(12, 6, 11) + T3(12, 7, 10);
+    c[8]  =  T3(4, 9, 15) - T3(4, 11, 13) - T3(8, 5, 15) + T3(8, 7, 13) + T3(12, 5, 11) - T3(12, 7, 9);
+    c[12] = -m[4] * m[9] * m[14] + T3(4, 10, 13) + T3(8, 5, 14) - T3(8, 6, 13) - T3(12, 5, 10) + T3(12, 6, 9);
+    c[1]  = -m[1] * m[10] * m[15] + T3(1, 11, 14) + T3(9, 2, 15) - T3(9, 3, 14) - T3(13, 2, 11) + T3(13, 3, 10);
+    c[5]  =  T3(0, 10, 15) - T3(0, 11, 14) - T3(8, 2, 15) + T3(8, 3, 14) + T3(12, 2, 11) - T3(12, 3, 10);
+    c[9]  = -m[0] * m[9] * m[15] + T3(0, 11, 13) + T3(8, 1, 15) - T3(8, 3, 13) - T3(12, 1, 11) + T3(12, 3, 9);
+    c[13] =  T3(0, 9, 14) - T3(0, 10, 13) - T3(8, 1, 14) + T3(8, 2, 13) + T3(12, 1, 10) - T3(12, 2, 9);
+    c[2]  =  T3(1, 6, 15) - T3(1, 7, 14) - T3(5, 2, 15) + T3(5, 3, 14) + T3(13, 2, 7) - T3(13, 3, 6);
+    c[6]  = -m[0] * m[6] * m[15] + T3(0, 7, 14) + T3(4, 2, 15) - T3(4, 3, 14) - T3(12, 2, 7) + T3(12, 3, 6);
+    c[10] =  T3(0, 5, 15) - T3(0, 7, 13) - T3(4, 1, 15) + T3(4, 3, 13) + T3(12, 1, 7) - T3(12, 3, 5);
+    c[14] = -m[0] * m[5] * m[14] + T3(0, 6, 13) + T3(4, 1, 14) - T3(4, 2, 13) - T3(12, 1, 6) + T3(12, 2, 5);
+    c[3]  = -m[1] * m[6] * m[11] + T3(1, 7, 10) + T3(5, 2, 11) - T3(5, 3, 10) - T3(9, 2, 7) + T3(9, 3, 6);
+    c[7]  =  T3(0, 6, 11) - T3(0, 7, 10) - T3(4, 2, 11) + T3(4, 3, 10) + T3(8, 2, 7) - T3(8, 3, 6);
+    c[11] = -m[0] * m[5] * m[11] + T3(0, 7, 9) + T3(4, 1, 11) - T3(4, 3, 9) - T3(8, 1, 7) + T3(8, 3, 5);
+    c[15] =  T3(0, 5, 10) - T3(0, 6, 9) - T3(4, 1, 10) + T3(4, 2, 9) + T3(8, 1, 6) - T3(8, 2, 5);
+
+    float det = m[0] * c[0] + m[1] * c[4] + m[2] * c[8] + m[3] * c[12];
+    if (det == 0) return 0;
+    det = (float)(1.0 / (double)det);
+    for (int i = 0; i < 16; ++i) inv_out[i] = c[i] * det;
+    return 1;
+}
+#undef T3
+
+/* cam2base = inverse(base2world) * cam2world.  Follows TSDF::TSDF (tsdf.cu:74) and
+ * TSDF::Integrate (tsdf.cu:139-142).  base2world_inv starts zeroed (tsdf.hpp:51) and a
+ * failed inversion is ignored by the reference, which this keeps. */
+void oracle_cam2base(const float *base2world, const float *cam2world, float *cam2base)
+{
+    float inv[16] = {0};
+    oracle_invert_matrix(base2world, inv);
+    oracle_multiply_matrix(inv, cam2world, cam2base);
+}
+
+/* ------------------------------------------------------------------------------------
+ * Surface point extraction.  Follows TSDF::SaveVoxelGrid2SurfacePointCloud,
+ * src/tsdf.cu:170-218: keep voxel i when fabs(tsdf) != 0 and weight > weight_thresh
+ * (tsdf_thresh is accepted and unused, as in the reference); point = origin + index*size.
+ * xyz may be NULL to count only.  Returns the number of points.
+ * ---------------------------------------------------------------------------------- */
+int64_t oracle_surface_points(const float *tsdf, const float *weight,
+                              int dim_x, int dim_y, int dim_z, float voxel_size,
+                              float origin_x, float origin_y, float origin_z,
+                              float tsdf_thresh, float weight_thresh, float *xyz)
+{
+    (void)tsdf_thresh;
+    int64_t n = 0;
+    for (int z = 0; z < dim_z; ++z)
+        for (int y = 0; y < dim_y; ++y)
+            for (int x = 0; x < dim_x; ++x) {
+                int64_t i = ((int64_t)z * dim_y + y) * dim_x + x;
+                if (fabsf(tsdf[i]) != 0.0f && weight[i] > weight_thresh) {
+                    if (xyz) {
+                        xyz[3 * n + 0] = origin_x + (float)x * voxel_size; /* tsdf.cu:206-208 */
+                        xyz[3 * n + 1] = origin_y + (float)y * voxel_size;
+                        xyz[3 * n + 2] = origin_z + (float)z * voxel_size;
+                    }
+                    ++n;
+                }
+            }
+    return n;
+}
+
+/* .ply writer: header text of tsdf.cu:185-192, then 3 floats per point (tsdf.cu:210-212). */
+int oracle_save_ply(const char *path, const float *tsdf, const float *weight,
+                    int dim_x, int dim_y, int dim_z, float voxel_size,
+                    float origin_x, float origin_y, float origin_z,
+                    float tsdf_thresh, float weight_thresh)
+{
+    int64_t n = oracle_surface_points(tsdf, weight, dim_x, dim_y, dim_z, voxel_size, origin_x,
+                                      origin_y, origin_z, tsdf_thresh, weight_thresh, NULL);
+    float *xyz = (float *)malloc(sizeof(float) * 3 * (size_t)(n ? n : 1));
+    if (!xyz) return -1;
+    oracle_surface_points(tsdf, weight, dim_x, dim_y, dim_z, voxel_size, origin_x, origin_y,
+                          origin_z, tsdf_thresh, weight_thresh, xyz);
+    FILE *fp = fopen(path, "w");
+    if (!fp) { free(xyz); return -1; }
+    fprintf(fp, "ply\n");
+    fprintf(fp, "format binary_little_endian 1.0\n");
+    fprintf(fp, "element vertex %d\n", (int)n);
+    fprintf(fp, "property float x\n");
+    fprintf(fp, "property float y\n");
+    fprintf(fp, "property float z\n");
+    fprintf(fp, "end_header\n");
+    fwrite(xyz, sizeof(float), 3 * (size_t)n, fp);
+    fclose(fp);
+    free(xyz);
+    return 0;
+}
+
+/* .bin writer: 8-float header {dim_x, dim_y, dim_z, origin xyz, voxel_size, trunc} then the
+ * TSDF floats; weights are not saved.  Follows TSDF::~TSDF, src/tsdf.cu:116-132. */
+int oracle_save_bin(const char *path, const float *tsdf, int dim_x, int dim_y, int dim_z,
+                    float origin_x, float origin_y, float origin_z,
+                    float voxel_size, float trunc_margin)
+{
+    FILE *fp = fopen(path, "wb");
+    if (!fp) return -1;
+    float hdr[8] = {(float)dim_x, (float)dim_y, (float)dim_z, origin_x, origin_y, origin_z,
+                    voxel_size, trunc_margin};
+    fwrite(hdr, sizeof(float), 8, fp);
+    fwrite(tsdf, sizeof(float), (size_t)dim_x * dim_y * dim_z, fp);
+    fclose(fp);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------
+ * Caller-side adapters.
+ * ---------------------------------------------------------------------------------- */
+
+/* TSDF origin of a new object: per-axis minimum over pixels with depth > 0 of the
+ * back-projected point, starting from 1000.  Follows Object::Object, src/Object.cpp:37-49
+ * (z is the raw depth value; x and y multiply by the reciprocal focal length). */
+void oracle_object_origin(const float *depth, int rows, int cols, const float *K, float *origin)
+{
+    origin[0] = origin[1] = origin[2] = 1000.0f;
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c) {
+            float z = depth[r * cols + c];
+            if (z <= 0.0) continue;
+            float x = ((float)c - K[2]) * z * (1.0f / K[0]);
+            float y = ((float)r - K[5]) * z * (1.0f / K[4]);
+            origin[0] = x < origin[0] ? x : origin[0];
+            origin[1] = y < origin[1] ? y : origin[1];
+            origin[2] = z < origin[2] ? z : origin[2];
+        }
+}
+
+/* Depth pre-processing of the offline labeller: keep raw values only at columns 0,3,6,..
+ * and rows 0,4,8,.., zero elsewhere, then scale by 1/factor in fp32.
+ * Follows examples/label_instance_rgbd.cpp:89-100 (factor 5000, config/TUM3.yaml:34). */
+void oracle_depth_prep(const uint16_t *raw, int rows, int cols, float factor, float *out)
+{
+    float scale = 1.0f / factor;
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c) {
+            float v = (r % 4 == 0 && c % 3 == 0) ? (float)raw[r * cols + c] : 0.0f;
+            out[r * cols + c] = v * scale;
+        }
+}
+
+/* Per-instance masking: depth * (mask/255) with an 8-bit mask whose values are {0,255}
+ * (src/MaskRCNN.cpp:354-357).  OpenCV's CV_8U division rounds to nearest, so 255 -> 1 and
+ * 0 -> 0 (other values, which the reference never produces, round at 127.5).
+ * Follows Engine::Run, src/Engine.cpp:192-193. */
+void oracle_mask_depth(const float *depth, const uint8_t *mask, int n, float *out)
+{
+    for (int i = 0; i < n; ++i) out[i] = depth[i] * (mask[i] >= 128 ? 1.0f : 0.0f);
+}
+
+int oracle_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

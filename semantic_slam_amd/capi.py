@@ -1,0 +1,261 @@
+"""ctypes binding of the C ABI in include/tsdf_hip.h (libtsdf_hip.so).
+
+This is plumbing for tests and bench.py: the same entry points a C++ caller reaches through
+include/tsdf.hpp.  There is no fallback of any kind here: if the shared library is missing
+or a call fails, a TsdfError is raised.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libtsdf_hip.so")
+
+# every symbol include/tsdf_hip.h declares (tests check the .so exports exactly these)
+ABI_SYMBOLS = [
+    "tsdf_config_default", "tsdf_create", "tsdf_destroy", "tsdf_reset", "tsdf_integrate",
+    "tsdf_integrate_device", "tsdf_integrate_cam2base", "tsdf_integrate_masked_device",
+    "tsdf_sync", "tsdf_download", "tsdf_upload", "tsdf_device_ptrs", "tsdf_slab_voxels",
+    "tsdf_get_config", "tsdf_last_cam2base", "tsdf_set_stream", "tsdf_get_stream",
+    "tsdf_count_surface", "tsdf_extract_surface", "tsdf_save_ply", "tsdf_save_bin",
+    "tsdf_integrate_sequence_timed", "tsdf_set_kernel_variant", "tsdf_last_error",
+    "tsdf_version", "tsdf_multiply_matrix", "tsdf_invert_matrix",
+]
+
+
+class TsdfError(RuntimeError):
+    pass
+
+
+class TsdfConfig(C.Structure):
+    """Mirror of `struct tsdf_config` (include/tsdf_hip.h)."""
+    _fields_ = [
+        ("im_height", C.c_int32), ("im_width", C.c_int32),
+        ("dim_x", C.c_int32), ("dim_y", C.c_int32), ("dim_z", C.c_int32),
+        ("z_begin", C.c_int32), ("z_end", C.c_int32),
+        ("voxel_size", C.c_float), ("trunc_margin", C.c_float), ("max_depth", C.c_float),
+        ("origin", C.c_float * 3), ("cam_K", C.c_float * 9), ("base2world", C.c_float * 16),
+        ("device", C.c_int32), ("id", C.c_int32),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Load libtsdf_hip.so (built by `make -C semantic_slam_amd/csrc` / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise TsdfError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, f32p, i64p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int64)
+    L.tsdf_config_default.argtypes = [C.POINTER(TsdfConfig), C.c_int32, C.c_int32]
+    L.tsdf_create.argtypes = [C.POINTER(TsdfConfig), C.POINTER(vp)]
+    L.tsdf_destroy.argtypes = [vp]
+    L.tsdf_reset.argtypes = [vp]
+    L.tsdf_integrate.argtypes = [vp, vp, vp]
+    L.tsdf_integrate_device.argtypes = [vp, vp, vp]
+    L.tsdf_integrate_cam2base.argtypes = [vp, vp, vp]
+    L.tsdf_integrate_masked_device.argtypes = [vp, vp, vp, vp]
+    L.tsdf_sync.argtypes = [vp]
+    L.tsdf_download.argtypes = [vp, vp, vp]
+    L.tsdf_upload.argtypes = [vp, vp, vp]
+    L.tsdf_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    L.tsdf_slab_voxels.argtypes = [vp]
+    L.tsdf_slab_voxels.restype = C.c_int64
+    L.tsdf_get_config.argtypes = [vp, C.POINTER(TsdfConfig)]
+    L.tsdf_last_cam2base.argtypes = [vp, vp]
+    L.tsdf_set_stream.argtypes = [vp, vp]
+    L.tsdf_get_stream.argtypes = [vp, C.POINTER(vp)]
+    L.tsdf_count_surface.argtypes = [vp, C.c_float, i64p]
+    L.tsdf_extract_surface.argtypes = [vp, C.c_float, vp, C.c_int64, i64p]
+    L.tsdf_save_ply.argtypes = [vp, C.c_char_p, C.c_float]
+    L.tsdf_save_bin.argtypes = [vp, C.c_char_p]
+    L.tsdf_integrate_sequence_timed.argtypes = [vp, vp, vp, C.c_int32, f32p]
+    L.tsdf_set_kernel_variant.argtypes = [vp, C.c_int32]
+    L.tsdf_last_error.restype = C.c_char_p
+    L.tsdf_version.restype = C.c_char_p
+    L.tsdf_multiply_matrix.argtypes = [vp, vp, vp]
+    L.tsdf_multiply_matrix.restype = None
+    L.tsdf_invert_matrix.argtypes = [vp, vp]
+    _lib = L
+    return L
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise TsdfError(f"{what} failed ({rc}): {load().tsdf_last_error().decode()}")
+
+
+def _f32(a, n=None):
+    a = np.ascontiguousarray(a, dtype=np.float32).ravel()
+    if n is not None and a.size != n:
+        raise ValueError(f"expected {n} floats, got {a.size}")
+    return a
+
+
+def default_config(im_height=480, im_width=640):
+    cfg = TsdfConfig()
+    check(load().tsdf_config_default(C.byref(cfg), im_height, im_width), "tsdf_config_default")
+    return cfg
+
+
+def make_config(dims, voxel_size, origin, trunc=None, K=None, base2world=None, z_begin=0, z_end=None,
+                im_height=480, im_width=640, max_depth=None, device=0, vol_id=0):
+    """Reference defaults (include/tsdf.hpp:63-67,96) with the given overrides."""
+    cfg = default_config(im_height, im_width)
+    cfg.dim_x, cfg.dim_y, cfg.dim_z = (int(d) for d in dims)
+    cfg.z_begin = int(z_begin)
+    cfg.z_end = int(cfg.dim_z if z_end is None else z_end)
+    cfg.voxel_size = voxel_size
+    # the reference's member initialiser: trunc_margin = voxel_size * 5 in fp32
+    cfg.trunc_margin = float(np.float32(voxel_size) * np.float32(5)) if trunc is None else trunc
+    if max_depth is not None:
+        cfg.max_depth = max_depth
+    cfg.origin[:] = [float(x) for x in _f32(origin, 3)]
+    if K is not None:
+        cfg.cam_K[:] = [float(x) for x in _f32(K, 9)]
+    if base2world is not None:
+        cfg.base2world[:] = [float(x) for x in _f32(base2world, 16)]
+    cfg.device = device
+    cfg.id = vol_id
+    return cfg
+
+
+def multiply_matrix(a, b):
+    out = np.empty(16, np.float32)
+    a, b = _f32(a, 16), _f32(b, 16)
+    load().tsdf_multiply_matrix(a.ctypes.data, b.ctypes.data, out.ctypes.data)
+    return out
+
+
+def invert_matrix(m):
+    out = np.zeros(16, np.float32)
+    m = _f32(m, 16)
+    ok = load().tsdf_invert_matrix(m.ctypes.data, out.ctypes.data)
+    return bool(ok), out
+
+
+class Volume:
+    """One z-slab of a TSDF grid in HBM: thin object wrapper over the opaque C handle."""
+
+    def __init__(self, cfg):
+        self.lib = load()
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        check(self.lib.tsdf_create(C.byref(cfg), C.byref(self._h)), "tsdf_create")
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self):
+        if self._h:
+            self.lib.tsdf_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- properties -------------------------------------------------------------------------
+    @property
+    def n_voxels(self):
+        return int(self.lib.tsdf_slab_voxels(self._h))
+
+    @property
+    def slab_shape(self):
+        c = self.cfg
+        return (c.z_end - c.z_begin, c.dim_y, c.dim_x)
+
+    def device_ptrs(self):
+        t, w = C.c_void_p(), C.c_void_p()
+        check(self.lib.tsdf_device_ptrs(self._h, C.byref(t), C.byref(w)), "tsdf_device_ptrs")
+        return t.value, w.value
+
+    # -- integrate --------------------------------------------------------------------------
+    def integrate(self, depth_host, cam2world):
+        """TSDF::Integrate semantics: host depth (borrowed for the call), camera pose."""
+        d = _f32(depth_host, self.cfg.im_height * self.cfg.im_width)
+        p = _f32(cam2world, 16)
+        check(self.lib.tsdf_integrate(self._h, d.ctypes.data, p.ctypes.data), "tsdf_integrate")
+
+    def integrate_device(self, depth_ptr, cam2world):
+        p = _f32(cam2world, 16)
+        check(self.lib.tsdf_integrate_device(self._h, depth_ptr, p.ctypes.data), "tsdf_integrate_device")
+
+    def integrate_cam2base(self, depth_ptr, cam2base):
+        p = _f32(cam2base, 16)
+        check(self.lib.tsdf_integrate_cam2base(self._h, depth_ptr, p.ctypes.data), "tsdf_integrate_cam2base")
+
+    def integrate_masked_device(self, depth_ptr, mask_ptr, cam2world):
+        p = _f32(cam2world, 16)
+        check(self.lib.tsdf_integrate_masked_device(self._h, depth_ptr, mask_ptr, p.ctypes.data),
+              "tsdf_integrate_masked_device")
+
+    def integrate_sequence_timed(self, depth_ptr, poses):
+        """Queue len(poses) frames back to back; returns device milliseconds (HIP events)."""
+        p = _f32(np.asarray(poses, dtype=np.float32))
+        n = p.size // 16
+        ms = C.c_float()
+        check(self.lib.tsdf_integrate_sequence_timed(self._h, depth_ptr, p.ctypes.data, n, C.byref(ms)),
+              "tsdf_integrate_sequence_timed")
+        return ms.value
+
+    def last_cam2base(self):
+        out = np.empty(16, np.float32)
+        check(self.lib.tsdf_last_cam2base(self._h, out.ctypes.data), "tsdf_last_cam2base")
+        return out
+
+    # -- state ------------------------------------------------------------------------------
+    def sync(self):
+        check(self.lib.tsdf_sync(self._h), "tsdf_sync")
+
+    def reset(self):
+        check(self.lib.tsdf_reset(self._h), "tsdf_reset")
+
+    def download(self):
+        n = self.n_voxels
+        t, w = np.empty(n, np.float32), np.empty(n, np.float32)
+        check(self.lib.tsdf_download(self._h, t.ctypes.data, w.ctypes.data), "tsdf_download")
+        return t, w
+
+    def upload(self, tsdf, weight):
+        t, w = _f32(tsdf, self.n_voxels), _f32(weight, self.n_voxels)
+        check(self.lib.tsdf_upload(self._h, t.ctypes.data, w.ctypes.data), "tsdf_upload")
+
+    def set_stream(self, stream_ptr):
+        check(self.lib.tsdf_set_stream(self._h, stream_ptr), "tsdf_set_stream")
+
+    def set_kernel_variant(self, v):
+        check(self.lib.tsdf_set_kernel_variant(self._h, v), "tsdf_set_kernel_variant")
+
+    # -- outputs ----------------------------------------------------------------------------
+    def count_surface(self, weight_thresh=0.9):
+        n = C.c_int64()
+        check(self.lib.tsdf_count_surface(self._h, weight_thresh, C.byref(n)), "tsdf_count_surface")
+        return n.value
+
+    def extract_surface(self, weight_thresh=0.9):
+        n = self.count_surface(weight_thresh)
+        xyz = np.empty((n, 3), np.float32)
+        got = C.c_int64()
+        check(self.lib.tsdf_extract_surface(self._h, weight_thresh, xyz.ctypes.data, n, C.byref(got)),
+              "tsdf_extract_surface")
+        assert got.value == n
+        return xyz
+
+    def save_ply(self, path, weight_thresh=0.9):
+        check(self.lib.tsdf_save_ply(self._h, os.fsencode(path), weight_thresh), "tsdf_save_ply")
+
+    def save_bin(self, path):
+        check(self.lib.tsdf_save_bin(self._h, os.fsencode(path)), "tsdf_save_bin")

@@ -1,0 +1,548 @@
+// tsdf_capi.hip -- implementation of include/tsdf_hip.h (libtsdf_hip.so).
+//
+// One handle = one z-slab of the voxel grid resident in HBM on one device + one HIP stream.
+// Host work per frame is the 4x4 pose composition (pose_math.h) and one kernel launch; the
+// depth frame is staged through a small ring of pinned buffers so the caller's pointer can be
+// released as soon as tsdf_integrate returns (ref: the reference's blocking cudaMemcpy of the
+// caller's buffer, src/tsdf.cu:162).
+//
+// There is no CPU fallback: without a HIP device every compute entry point fails with
+// TSDF_ERR_NO_DEVICE / TSDF_ERR_HIP.
+#include "../../include/tsdf_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "pose_math.h"
+#include "tsdf_kernels.hip.h"
+#include "tsdf_extract.hip.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return fail(TSDF_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),   \
+                        __FILE__, __LINE__);                                                   \
+    } while (0)
+
+constexpr int kStageSlots = 3;
+
+}  // namespace
+
+struct tsdf_volume {
+    tsdf_config cfg;
+    float base2world_inv[16];
+    float last_cam2base[16];
+    int64_t n_vox;           // voxels in the slab
+    float *d_tsdf;
+    float *d_weight;
+    hipStream_t own_stream;
+    hipStream_t stream;      // the stream work is queued on (own_stream unless overridden)
+    // host->device staging of depth frames
+    float *h_stage[kStageSlots];
+    float *d_stage[kStageSlots];
+    hipEvent_t stage_done[kStageSlots];
+    bool stage_used[kStageSlots];
+    int stage_next;
+    int variant;
+    // scratch for surface extraction (allocated on first use)
+    void *d_scratch;
+    size_t scratch_bytes;
+};
+
+namespace {
+
+int bind_device(const tsdf_volume *v)
+{
+    HIP_TRY(hipSetDevice(v->cfg.device));
+    return TSDF_OK;
+}
+
+tsdfk::IntegrateParams make_params(const tsdf_volume *v, const float *depth_dev,
+                                   const uint8_t *mask_dev, const float *c2b, int vx)
+{
+    const tsdf_config &c = v->cfg;
+    tsdfk::IntegrateParams p;
+    p.depth = depth_dev;
+    p.mask = mask_dev;
+    p.tsdf = v->d_tsdf;
+    p.weight = v->d_weight;
+    p.fx = c.cam_K[0]; p.fy = c.cam_K[4]; p.cx = c.cam_K[2]; p.cy = c.cam_K[5];
+    p.rx0 = c2b[0]; p.rx1 = c2b[4]; p.rx2 = c2b[8];
+    p.ry0 = c2b[1]; p.ry1 = c2b[5]; p.ry2 = c2b[9];
+    p.rz0 = c2b[2]; p.rz1 = c2b[6]; p.rz2 = c2b[10];
+    p.tx = c2b[3]; p.ty = c2b[7]; p.tz = c2b[11];
+    p.ox = c.origin[0]; p.oy = c.origin[1]; p.oz = c.origin[2];
+    p.vs = c.voxel_size; p.trunc = c.trunc_margin; p.max_depth = c.max_depth;
+    p.dim_x = c.dim_x; p.dim_y = c.dim_y;
+    p.nz = c.z_end - c.z_begin; p.z_begin = c.z_begin;
+    p.H = c.im_height; p.W = c.im_width;
+    p.xgroups = (c.dim_x + vx - 1) / vx;
+    return p;
+}
+
+// Queue one Integrate launch.  Shapes are validated at tsdf_create, so the grid below covers
+// exactly the slab and every access stays inside the two allocations.
+int launch_integrate(tsdf_volume *v, const float *depth_dev, const uint8_t *mask_dev,
+                     const float *c2b)
+{
+    const tsdf_config &c = v->cfg;
+    const int nz = c.z_end - c.z_begin;
+    if (nz == 0) return TSDF_OK;  // empty slab: nothing to do
+    std::memcpy(v->last_cam2base, c2b, sizeof v->last_cam2base);
+    const bool vec4 = (c.dim_x % 4 == 0) && v->variant != 1;
+    const int vx = vec4 ? 4 : 1;
+    tsdfk::IntegrateParams p = make_params(v, depth_dev, mask_dev, c2b, vx);
+    dim3 block(64, 4, 1);
+    dim3 grid((p.xgroups + 63) / 64, (c.dim_y + 3) / 4, nz);
+    if (vec4) {
+        if (mask_dev) hipLaunchKernelGGL((tsdfk::integrate_rows<4, true>), grid, block, 0, v->stream, p);
+        else hipLaunchKernelGGL((tsdfk::integrate_rows<4, false>), grid, block, 0, v->stream, p);
+    } else {
+        if (mask_dev) hipLaunchKernelGGL((tsdfk::integrate_rows<1, true>), grid, block, 0, v->stream, p);
+        else hipLaunchKernelGGL((tsdfk::integrate_rows<1, false>), grid, block, 0, v->stream, p);
+    }
+    HIP_TRY(hipGetLastError());
+    return TSDF_OK;
+}
+
+void compose_cam2base(const tsdf_volume *v, const float *cam2world, float *c2b)
+{
+    tsdf_host::multiply_matrix(v->base2world_inv, cam2world, c2b);  // ref: src/tsdf.cu:142
+}
+
+int fill(tsdf_volume *v)
+{
+    if (v->n_vox == 0) return TSDF_OK;
+    size_t n = (size_t)v->n_vox;
+    int blocks = (int)std::min<size_t>((n / 4 + 255) / 256, 256 * 8);
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(tsdfk::fill_grid, dim3(blocks), dim3(256), 0, v->stream, v->d_tsdf, v->d_weight, n);
+    HIP_TRY(hipGetLastError());
+    return TSDF_OK;
+}
+
+int ensure_scratch(tsdf_volume *v, size_t bytes)
+{
+    if (v->scratch_bytes >= bytes) return TSDF_OK;
+    if (v->d_scratch) HIP_TRY(hipFree(v->d_scratch));
+    v->d_scratch = nullptr;
+    v->scratch_bytes = 0;
+    HIP_TRY(hipMalloc(&v->d_scratch, bytes));
+    v->scratch_bytes = bytes;
+    return TSDF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *tsdf_last_error(void) { return g_last_error.c_str(); }
+
+const char *tsdf_version(void) { return "tsdf_hip 0.1 (gfx950)"; }
+
+void tsdf_multiply_matrix(const float a[16], const float b[16], float out[16])
+{
+    tsdf_host::multiply_matrix(a, b, out);
+}
+
+int tsdf_invert_matrix(const float m[16], float inv_out[16])
+{
+    return tsdf_host::invert_matrix(m, inv_out) ? 1 : 0;
+}
+
+int tsdf_config_default(tsdf_config *cfg, int32_t im_height, int32_t im_width)
+{
+    if (!cfg) return fail(TSDF_ERR_INVALID, "tsdf_config_default: cfg is NULL");
+    std::memset(cfg, 0, sizeof *cfg);
+    cfg->im_height = im_height;
+    cfg->im_width = im_width;
+    cfg->dim_x = cfg->dim_y = cfg->dim_z = 200;  // ref: include/tsdf.hpp:65-67
+    cfg->z_begin = 0;
+    cfg->z_end = 200;
+    cfg->voxel_size = 0.004f;                    // ref: include/tsdf.hpp:63
+    cfg->trunc_margin = cfg->voxel_size * 5;     // ref: include/tsdf.hpp:64
+    cfg->max_depth = 6.0f;                       // ref: src/tsdf.cu:46
+    const float K[9] = {535.4f, 0, 320.1f, 0, 539.2f, 247.6f, 0, 0, 1};  // ref: include/tsdf.hpp:96
+    std::memcpy(cfg->cam_K, K, sizeof K);
+    for (int i = 0; i < 4; ++i) cfg->base2world[5 * i] = 1.0f;
+    return TSDF_OK;
+}
+
+int tsdf_create(const tsdf_config *cfg, tsdf_volume **out)
+{
+    if (!cfg || !out) return fail(TSDF_ERR_INVALID, "tsdf_create: NULL argument");
+    *out = nullptr;
+    if (cfg->dim_x <= 0 || cfg->dim_y <= 0 || cfg->dim_z <= 0)
+        return fail(TSDF_ERR_INVALID, "tsdf_create: grid dims must be positive (%d,%d,%d)",
+                    cfg->dim_x, cfg->dim_y, cfg->dim_z);
+    if (cfg->z_begin < 0 || cfg->z_end < cfg->z_begin || cfg->z_end > cfg->dim_z)
+        return fail(TSDF_ERR_INVALID, "tsdf_create: slab [%d,%d) outside grid z range [0,%d)",
+                    cfg->z_begin, cfg->z_end, cfg->dim_z);
+    if (cfg->im_height <= 0 || cfg->im_width <= 0 ||
+        (int64_t)cfg->im_height * cfg->im_width > (int64_t)1 << 30)
+        return fail(TSDF_ERR_INVALID, "tsdf_create: bad image size %dx%d", cfg->im_height, cfg->im_width);
+    if (!(cfg->voxel_size > 0.0f) || !(cfg->trunc_margin > 0.0f))
+        return fail(TSDF_ERR_INVALID, "tsdf_create: voxel_size and trunc_margin must be > 0");
+    if (cfg->dim_y > 65535 * 4 || (cfg->z_end - cfg->z_begin) > 65535)
+        return fail(TSDF_ERR_INVALID, "tsdf_create: slab exceeds launch limits (dim_y <= 262140, slices <= 65535)");
+
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+        return fail(TSDF_ERR_NO_DEVICE, "tsdf_create: no HIP device visible (this library has no CPU path)");
+    if (cfg->device < 0 || cfg->device >= n_dev)
+        return fail(TSDF_ERR_INVALID, "tsdf_create: device %d not in [0,%d)", cfg->device, n_dev);
+
+    tsdf_volume *v = new (std::nothrow) tsdf_volume();
+    if (!v) return fail(TSDF_ERR_INVALID, "tsdf_create: out of host memory");
+    std::memset(v, 0, sizeof *v);
+    v->cfg = *cfg;
+    v->n_vox = (int64_t)cfg->dim_x * cfg->dim_y * (cfg->z_end - cfg->z_begin);
+    // ref: src/tsdf.cu:74 -- the inverse stays zero when base2world is singular, silently
+    std::memset(v->base2world_inv, 0, sizeof v->base2world_inv);
+    tsdf_host::invert_matrix(cfg->base2world, v->base2world_inv);
+
+    int rc = TSDF_OK;
+    auto cleanup = [&](int code) { tsdf_destroy(v); return code; };
+    if (hipSetDevice(cfg->device) != hipSuccess)
+        return cleanup(fail(TSDF_ERR_HIP, "tsdf_create: hipSetDevice(%d) failed", cfg->device));
+    hipError_t e;
+    if ((e = hipStreamCreateWithFlags(&v->own_stream, hipStreamNonBlocking)) != hipSuccess)
+        return cleanup(fail(TSDF_ERR_HIP, "tsdf_create: hipStreamCreate: %s", hipGetErrorString(e)));
+    v->stream = v->own_stream;
+    size_t bytes = (size_t)(v->n_vox > 0 ? v->n_vox : 1) * sizeof(float);
+    if ((e = hipMalloc((void **)&v->d_tsdf, bytes)) != hipSuccess ||
+        (e = hipMalloc((void **)&v->d_weight, bytes)) != hipSuccess)
+        return cleanup(fail(TSDF_ERR_HIP, "tsdf_create: hipMalloc of %zu bytes x2: %s", bytes, hipGetErrorString(e)));
+    size_t img = (size_t)cfg->im_height * cfg->im_width * sizeof(float);
+    for (int i = 0; i < kStageSlots; ++i) {
+        if ((e = hipHostMalloc((void **)&v->h_stage[i], img, hipHostMallocDefault)) != hipSuccess ||
+            (e = hipMalloc((void **)&v->d_stage[i], img)) != hipSuccess ||
+            (e = hipEventCreateWithFlags(&v->stage_done[i], hipEventDisableTiming)) != hipSuccess)
+            return cleanup(fail(TSDF_ERR_HIP, "tsdf_create: staging alloc: %s", hipGetErrorString(e)));
+    }
+    if ((rc = fill(v)) != TSDF_OK) return cleanup(rc);
+    *out = v;
+    return TSDF_OK;
+}
+
+int tsdf_destroy(tsdf_volume *v)
+{
+    if (!v) return TSDF_OK;
+    (void)hipSetDevice(v->cfg.device);
+    if (v->own_stream) (void)hipStreamSynchronize(v->own_stream);
+    if (v->stream && v->stream != v->own_stream) (void)hipStreamSynchronize(v->stream);
+    for (int i = 0; i < kStageSlots; ++i) {
+        if (v->stage_done[i]) (void)hipEventDestroy(v->stage_done[i]);
+        if (v->h_stage[i]) (void)hipHostFree(v->h_stage[i]);
+        if (v->d_stage[i]) (void)hipFree(v->d_stage[i]);
+    }
+    if (v->d_scratch) (void)hipFree(v->d_scratch);
+    if (v->d_tsdf) (void)hipFree(v->d_tsdf);
+    if (v->d_weight) (void)hipFree(v->d_weight);
+    if (v->own_stream) (void)hipStreamDestroy(v->own_stream);
+    delete v;
+    return TSDF_OK;
+}
+
+int tsdf_reset(tsdf_volume *v)
+{
+    if (!v) return fail(TSDF_ERR_INVALID, "tsdf_reset: NULL handle");
+    int rc = bind_device(v);
+    if (rc) return rc;
+    return fill(v);
+}
+
+int tsdf_integrate(tsdf_volume *v, const float *depth_host, const float cam2world[16])
+{
+    if (!v || !depth_host || !cam2world) return fail(TSDF_ERR_INVALID, "tsdf_integrate: NULL argument");
+    int rc = bind_device(v);
+    if (rc) return rc;
+    const int s = v->stage_next;
+    v->stage_next = (s + 1) % kStageSlots;
+    if (v->stage_used[s]) HIP_TRY(hipEventSynchronize(v->stage_done[s]));  // slot's last kernel done
+    size_t img = (size_t)v->cfg.im_height * v->cfg.im_width * sizeof(float);
+    std::memcpy(v->h_stage[s], depth_host, img);  // caller may free depth_host after we return
+    HIP_TRY(hipMemcpyAsync(v->d_stage[s], v->h_stage[s], img, hipMemcpyHostToDevice, v->stream));
+    float c2b[16];
+    compose_cam2base(v, cam2world, c2b);
+    rc = launch_integrate(v, v->d_stage[s], nullptr, c2b);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(v->stage_done[s], v->stream));
+    v->stage_used[s] = true;
+    return TSDF_OK;
+}
+
+int tsdf_integrate_device(tsdf_volume *v, const float *depth_dev, const float cam2world[16])
+{
+    if (!v || !depth_dev || !cam2world) return fail(TSDF_ERR_INVALID, "tsdf_integrate_device: NULL argument");
+    int rc = bind_device(v);
+    if (rc) return rc;
+    float c2b[16];
+    compose_cam2base(v, cam2world, c2b);
+    return launch_integrate(v, depth_dev, nullptr, c2b);
+}
+
+int tsdf_integrate_cam2base(tsdf_volume *v, const float *depth_dev, const float cam2base[16])
+{
+    if (!v || !depth_dev || !cam2base) return fail(TSDF_ERR_INVALID, "tsdf_integrate_cam2base: NULL argument");
+    int rc = bind_device(v);
+    if (rc) return rc;
+    return launch_integrate(v, depth_dev, nullptr, cam2base);
+}
+
+int tsdf_integrate_masked_device(tsdf_volume *v, const float *depth_dev, const uint8_t *mask_dev,
+                                 const float cam2world[16])
+{
+    if (!v || !depth_dev || !mask_dev || !cam2world)
+        return fail(TSDF_ERR_INVALID, "tsdf_integrate_masked_device: NULL argument");
+    int rc = bind_device(v);
+    if (rc) return rc;
+    float c2b[16];
+    compose_cam2base(v, cam2world, c2b);
+    return launch_integrate(v, depth_dev, mask_dev, c2b);
+}
+
+int tsdf_sync(tsdf_volume *v)
+{
+    if (!v) return fail(TSDF_ERR_INVALID, "tsdf_sync: NULL handle");
+    int rc = bind_device(v);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(v->stream));
+    return TSDF_OK;
+}
+
+int tsdf_download(tsdf_volume *v, float *tsdf_host, float *weight_host)
+{
+    if (!v) return fail(TSDF_ERR_INVALID, "tsdf_download: NULL handle");
+    int rc = bind_device(v);
+    if (rc) return rc;
+    size_t bytes = (size_t)v->n_vox * sizeof(float);
+    HIP_TRY(hipStreamSynchronize(v->stream));
+    if (bytes == 0) return TSDF_OK;
+    if (tsdf_host) HIP_TRY(hipMemcpy(tsdf_host, v->d_tsdf, bytes, hipMemcpyDeviceToHost));
+    if (weight_host) HIP_TRY(hipMemcpy(weight_host, v->d_weight, bytes, hipMemcpyDeviceToHost));
+    return TSDF_OK;
+}
+
+int tsdf_upload(tsdf_volume *v, const float *tsdf_host, const float *weight_host)
+{
+    if (!v) return fail(TSDF_ERR_INVALID, "tsdf_upload: NULL handle");
+    int rc = bind_device(v);
+    if (rc) return rc;
+    size_t bytes = (size_t)v->n_vox * sizeof(float);
+    HIP_TRY(hipStreamSynchronize(v->stream));
+    if (bytes == 0) return TSDF_OK;
+    if (tsdf_host) HIP_TRY(hipMemcpy(v->d_tsdf, tsdf_host, bytes, hipMemcpyHostToDevice));
+    if (weight_host) HIP_TRY(hipMemcpy(v->d_weight, weight_host, bytes, hipMemcpyHostToDevice));
+    return TSDF_OK;
+}
+
+int tsdf_device_ptrs(tsdf_volume *v, float **tsdf_dev, float **weight_dev)
+{
+    if (!v) return fail(TSDF_ERR_INVALID, "tsdf_device_ptrs: NULL handle");
+    if (tsdf_dev) *tsdf_dev = v->d_tsdf;
+    if (weight_dev) *weight_dev = v->d_weight;
+    return TSDF_OK;
+}
+
+int64_t tsdf_slab_voxels(const tsdf_volume *v) { return v ? v->n_vox : 0; }
+
+int tsdf_get_config(const tsdf_volume *v, tsdf_config *out)
+{
+    if (!v || !out) return fail(TSDF_ERR_INVALID, "tsdf_get_config: NULL argument");
+    *out = v->cfg;
+    return TSDF_OK;
+}
+
+int tsdf_last_cam2base(const tsdf_volume *v, float out[16])
+{
+    if (!v || !out) return fail(TSDF_ERR_INVALID, "tsdf_last_cam2base: NULL argument");
+    std::memcpy(out, v->last_cam2base, sizeof v->last_cam2base);
+    return TSDF_OK;
+}
+
+int tsdf_set_stream(tsdf_volume *v, void *hip_stream)
+{
+    if (!v) return fail(TSDF_ERR_INVALID, "tsdf_set_stream: NULL handle");
+    int rc = bind_device(v);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(v->stream));  // do not reorder against work already queued
+    v->stream = hip_stream ? (hipStream_t)hip_stream : v->own_stream;
+    return TSDF_OK;
+}
+
+int tsdf_get_stream(tsdf_volume *v, void **hip_stream)
+{
+    if (!v || !hip_stream) return fail(TSDF_ERR_INVALID, "tsdf_get_stream: NULL argument");
+    *hip_stream = (void *)v->stream;
+    return TSDF_OK;
+}
+
+int tsdf_set_kernel_variant(tsdf_volume *v, int32_t variant)
+{
+    if (!v) return fail(TSDF_ERR_INVALID, "tsdf_set_kernel_variant: NULL handle");
+    if (variant < 0 || variant > 1) return fail(TSDF_ERR_INVALID, "tsdf_set_kernel_variant: unknown variant %d", variant);
+    v->variant = variant;
+    return TSDF_OK;
+}
+
+int tsdf_integrate_sequence_timed(tsdf_volume *v, const float *depth_dev, const float *cam2world,
+                                  int32_t n_frames, float *elapsed_ms)
+{
+    if (!v || !depth_dev || !cam2world || n_frames <= 0 || !elapsed_ms)
+        return fail(TSDF_ERR_INVALID, "tsdf_integrate_sequence_timed: bad argument");
+    int rc = bind_device(v);
+    if (rc) return rc;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, v->stream));
+    for (int k = 0; k < n_frames && rc == TSDF_OK; ++k) {
+        float c2b[16];
+        compose_cam2base(v, cam2world + 16 * k, c2b);
+        rc = launch_integrate(v, depth_dev, nullptr, c2b);
+    }
+    hipError_t er = hipEventRecord(e1, v->stream);
+    hipError_t es = hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipError_t et = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    if (er != hipSuccess || es != hipSuccess || et != hipSuccess)
+        return fail(TSDF_ERR_HIP, "tsdf_integrate_sequence_timed: event timing failed");
+    *elapsed_ms = ms;
+    return TSDF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// surface extraction (ref: src/tsdf.cu:170-218), on the device
+// ---------------------------------------------------------------------------------------------
+static int surface_pass(tsdf_volume *v, float weight_thresh, float *xyz_host, int64_t capacity,
+                        int64_t *count)
+{
+    int rc = bind_device(v);
+    if (rc) return rc;
+    *count = 0;
+    if (v->n_vox == 0) return TSDF_OK;
+    const int64_t n = v->n_vox;
+    const int64_t n_chunks = (n + tsdfx::kChunk - 1) / tsdfx::kChunk;
+    if (n_chunks > 0x7fffffff) return fail(TSDF_ERR_INVALID, "surface extraction: slab too large");
+    // scratch: per-chunk counts (u32) then per-chunk offsets (i64) then total (i64)
+    size_t off_counts = 0;
+    size_t off_offsets = ((size_t)n_chunks * sizeof(uint32_t) + 255) & ~(size_t)255;
+    size_t off_total = off_offsets + (size_t)n_chunks * sizeof(int64_t);
+    size_t need = off_total + 256;
+    rc = ensure_scratch(v, need);
+    if (rc) return rc;
+    char *s = (char *)v->d_scratch;
+    uint32_t *d_counts = (uint32_t *)(s + off_counts);
+    int64_t *d_offsets = (int64_t *)(s + off_offsets);
+    int64_t *d_total = (int64_t *)(s + off_total);
+
+    hipLaunchKernelGGL(tsdfx::surface_count, dim3((unsigned)n_chunks), dim3(256), 0, v->stream,
+                       v->d_tsdf, v->d_weight, n, weight_thresh, d_counts);
+    hipLaunchKernelGGL(tsdfx::scan_counts, dim3(1), dim3(1024), 0, v->stream, d_counts, n_chunks,
+                       d_offsets, d_total);
+    HIP_TRY(hipGetLastError());
+    int64_t total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, d_total, sizeof total, hipMemcpyDeviceToHost, v->stream));
+    HIP_TRY(hipStreamSynchronize(v->stream));
+    *count = total;
+    if (!xyz_host || capacity <= 0 || total == 0) return TSDF_OK;
+
+    int64_t n_out = total < capacity ? total : capacity;
+    float *d_xyz = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_xyz, (size_t)total * 3 * sizeof(float)));
+    const tsdf_config &c = v->cfg;
+    hipLaunchKernelGGL(tsdfx::surface_emit, dim3((unsigned)n_chunks), dim3(256), 0, v->stream,
+                       v->d_tsdf, v->d_weight, n, weight_thresh, d_offsets, c.dim_x, c.dim_y,
+                       c.z_begin, c.origin[0], c.origin[1], c.origin[2], c.voxel_size, d_xyz);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(xyz_host, d_xyz, (size_t)n_out * 3 * sizeof(float), hipMemcpyDeviceToHost, v->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(v->stream);
+    (void)hipFree(d_xyz);
+    if (e != hipSuccess) return fail(TSDF_ERR_HIP, "surface extraction: %s", hipGetErrorString(e));
+    return TSDF_OK;
+}
+
+int tsdf_count_surface(tsdf_volume *v, float weight_thresh, int64_t *count)
+{
+    if (!v || !count) return fail(TSDF_ERR_INVALID, "tsdf_count_surface: NULL argument");
+    return surface_pass(v, weight_thresh, nullptr, 0, count);
+}
+
+int tsdf_extract_surface(tsdf_volume *v, float weight_thresh, float *xyz_host, int64_t capacity,
+                         int64_t *count)
+{
+    if (!v || !count) return fail(TSDF_ERR_INVALID, "tsdf_extract_surface: NULL argument");
+    return surface_pass(v, weight_thresh, xyz_host, capacity, count);
+}
+
+int tsdf_save_ply(tsdf_volume *v, const char *path, float weight_thresh)
+{
+    if (!v || !path) return fail(TSDF_ERR_INVALID, "tsdf_save_ply: NULL argument");
+    int64_t n = 0;
+    int rc = surface_pass(v, weight_thresh, nullptr, 0, &n);
+    if (rc) return rc;
+    std::vector<float> xyz((size_t)(n > 0 ? n : 1) * 3);
+    if (n > 0) {
+        rc = surface_pass(v, weight_thresh, xyz.data(), n, &n);
+        if (rc) return rc;
+    }
+    FILE *fp = std::fopen(path, "w");
+    if (!fp) return fail(TSDF_ERR_IO, "tsdf_save_ply: cannot open %s", path);
+    // header text of ref: src/tsdf.cu:185-192 (the vertex count is printed with %d there)
+    std::fprintf(fp, "ply\nformat binary_little_endian 1.0\nelement vertex %d\n", (int)n);
+    std::fprintf(fp, "property float x\nproperty float y\nproperty float z\nend_header\n");
+    size_t wrote = std::fwrite(xyz.data(), sizeof(float), (size_t)n * 3, fp);
+    int bad = std::fclose(fp);
+    if (wrote != (size_t)n * 3 || bad) return fail(TSDF_ERR_IO, "tsdf_save_ply: short write to %s", path);
+    return TSDF_OK;
+}
+
+int tsdf_save_bin(tsdf_volume *v, const char *path)
+{
+    if (!v || !path) return fail(TSDF_ERR_INVALID, "tsdf_save_bin: NULL argument");
+    std::vector<float> host((size_t)(v->n_vox > 0 ? v->n_vox : 1));
+    int rc = tsdf_download(v, host.data(), nullptr);
+    if (rc) return rc;
+    FILE *fp = std::fopen(path, "wb");
+    if (!fp) return fail(TSDF_ERR_IO, "tsdf_save_bin: cannot open %s", path);
+    const tsdf_config &c = v->cfg;
+    // ref: src/tsdf.cu:119-129 -- dims as floats, origin, voxel size, truncation margin
+    float hdr[8] = {(float)c.dim_x, (float)c.dim_y, (float)(c.z_end - c.z_begin),
+                    c.origin[0], c.origin[1], c.origin[2], c.voxel_size, c.trunc_margin};
+    size_t ok = std::fwrite(hdr, sizeof(float), 8, fp);
+    ok += std::fwrite(host.data(), sizeof(float), (size_t)v->n_vox, fp);  // one write, not one per float
+    int bad = std::fclose(fp);
+    if (ok != 8 + (size_t)v->n_vox || bad) return fail(TSDF_ERR_IO, "tsdf_save_bin: short write to %s", path);
+    return TSDF_OK;
+}
+
+}  // extern "C"

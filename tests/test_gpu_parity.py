@@ -1,0 +1,276 @@
+"""GPU parity: the HIP Integrate path, called through the C ABI, against the CPU oracle.
+
+Bar: BIT-EXACT fp32 (stronger than the 1e-5 relative tolerance BASELINE.json states).  The
+kernel keeps the reference's operation order, IEEE division and no FMA contraction, so every
+TSDF and weight value must equal the oracle's bit for bit; the tolerance form
+abs(d) <= 1e-5*max(abs(ref),1) is asserted as well so a regression reports how far off it is.
+"""
+import numpy as np
+import pytest
+
+from semantic_slam_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5  # BASELINE.json north_star: "SDF/weight within 1e-5 rel of CPU reference"
+
+
+def assert_parity(got_t, got_w, ref_t, ref_w):
+    assert np.array_equal(got_w, ref_w), f"weights differ at {np.flatnonzero(got_w != ref_w)[:5]}"
+    err = np.abs(got_t.astype(np.float64) - ref_t)
+    assert np.all(err <= TOL * np.maximum(np.abs(ref_t), 1.0)), f"max abs err {err.max()}"
+    nbad = int(np.count_nonzero(got_t.view(np.uint32) != ref_t.view(np.uint32)))
+    assert nbad == 0, f"{nbad} of {got_t.size} TSDF values not bit-identical"
+
+
+def dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+CASES = [
+    # dims, voxel, z0, base pose random?, frames
+    ((64, 64, 64), 0.01, 0.8, False, 4),
+    ((48, 40, 36), 0.02, 0.5, True, 5),
+    ((200, 200, 40), 0.004, 0.6, True, 3),     # reference default row length / voxel size
+    ((37, 29, 31), 0.02, 0.7, True, 4),        # dim_x % 4 != 0 -> scalar kernel
+    ((256, 8, 8), 0.004, 1.0, False, 3),       # one full wavefront per row
+    ((4, 4, 4), 0.05, 1.0, False, 2),          # tiny
+    ((300, 5, 3), 0.003, 0.9, True, 3),        # ragged: partial wavefronts and partial blocks
+]
+
+
+@pytest.mark.parametrize("dims,vs,z0,rand_base,frames", CASES)
+def test_integrate_matches_oracle(cuda, oracle, dims, vs, z0, rand_base, frames):
+    rng = np.random.default_rng(hash((dims, frames)) & 0xffff)
+    origin = synth.surf_volume(max(dims), vs, z0)
+    base = synth.random_pose(rng) if rand_base else synth.identity_pose()
+    cfg = capi.make_config(dims, vs, origin, base2world=base)
+    scene = synth.SurfScene(dims, vs, origin)
+    ref_t, ref_w = oracle.init_grid(dims)
+    with capi.Volume(cfg) as vol:
+        t0, w0 = vol.download()
+        assert np.all(t0 == 1.0) and np.all(w0 == 0.0)  # ref: src/tsdf.cu:79-81
+        n_upd = 0
+        for k in range(frames):
+            c2w = synth.random_pose(rng, 0.35, 0.4)
+            c2b = oracle.cam2base(base, c2w)
+            depth = scene.depth(c2b, quantize=bool(k & 1))
+            # a few invalid samples: zero, negative, beyond the 6 m cut-off (ref: src/tsdf.cu:46)
+            ys, xs = rng.integers(0, 480, 300), rng.integers(0, 640, 300)
+            depth[ys[:100], xs[:100]] = 0.0
+            depth[ys[100:200], xs[100:200]] = -1.0
+            depth[ys[200:], xs[200:]] = 6.5
+            d_dev = dev(cuda, depth)
+            vol.integrate_device(d_dev.data_ptr(), c2w)
+            assert np.array_equal(vol.last_cam2base(), c2b), "host pose composition differs from the oracle"
+            n_upd += oracle.integrate(cfg.cam_K, c2b, depth, dims, origin, vs, cfg.trunc_margin, ref_t, ref_w)
+            vol.sync()
+        got_t, got_w = vol.download()
+    assert n_upd > 0, "test scene updated nothing: not a test"
+    assert_parity(got_t, got_w, ref_t, ref_w)
+
+
+def test_host_depth_path_equals_device_path(cuda, oracle):
+    """tsdf_integrate (TSDF::Integrate semantics, host pointer) == device-resident path."""
+    dims, vs = (64, 48, 40), 0.01
+    origin = synth.surf_volume(64, vs, 0.7)
+    cfg = capi.make_config(dims, vs, origin)
+    scene = synth.SurfScene(dims, vs, origin)
+    ref_t, ref_w = oracle.init_grid(dims)
+    with capi.Volume(cfg) as vol:
+        for k in range(7):  # more frames than staging slots: exercises slot reuse
+            c2w = scene.pose(k, n=7)
+            depth = scene.depth(c2w)
+            tmp = depth.copy()
+            vol.integrate(tmp, c2w)
+            tmp[:] = -5.0  # caller may reuse its buffer as soon as the call returns
+            oracle.integrate(cfg.cam_K, c2w, depth, dims, origin, vs, cfg.trunc_margin, ref_t, ref_w)
+        got_t, got_w = vol.download()
+    assert_parity(got_t, got_w, ref_t, ref_w)
+
+
+def test_zslabs_equal_whole_grid(cuda, oracle):
+    """Two z-slab handles == one whole-grid handle, bit for bit (global z in the kernel)."""
+    dims, vs = (64, 32, 50), 0.013
+    origin = synth.surf_volume(64, vs, 0.6)
+    scene = synth.SurfScene(dims, vs, origin)
+    cuts = [0, 17, 17, 50]  # includes an empty slab
+    slabs = [capi.Volume(capi.make_config(dims, vs, origin, z_begin=a, z_end=b))
+             for a, b in zip(cuts[:-1], cuts[1:])]
+    whole = capi.Volume(capi.make_config(dims, vs, origin))
+    ref_t, ref_w = oracle.init_grid(dims)
+    for k in range(3):
+        c2w = scene.pose(k, n=3)
+        d_dev = dev(cuda, scene.depth(c2w))
+        for v in slabs + [whole]:
+            v.integrate_device(d_dev.data_ptr(), c2w)
+            v.sync()
+        oracle.integrate(whole.cfg.cam_K, c2w, scene.depth(c2w), dims, origin, vs,
+                         whole.cfg.trunc_margin, ref_t, ref_w)
+    parts = [v.download() for v in slabs]
+    t = np.concatenate([p[0] for p in parts])
+    w = np.concatenate([p[1] for p in parts])
+    wt, ww = whole.download()
+    assert_parity(t, w, wt, ww)
+    assert_parity(t, w, ref_t, ref_w)
+    # and the oracle's own slab form agrees with its whole-grid form
+    st, sw = oracle.init_grid(dims, 17, 50)
+    for k in range(3):
+        c2w = scene.pose(k, n=3)
+        oracle.integrate(whole.cfg.cam_K, c2w, scene.depth(c2w), dims, origin, vs,
+                         whole.cfg.trunc_margin, st, sw, z_begin=17, z_end=50)
+    assert np.array_equal(st, ref_t[17 * 32 * 64:]) and np.array_equal(sw, ref_w[17 * 32 * 64:])
+    for v in slabs + [whole]:
+        v.close()
+
+
+def test_masked_integrate(cuda, oracle):
+    """depth * (mask/255) fused into the kernel == oracle on the pre-multiplied image."""
+    dims, vs = (64, 64, 32), 0.01
+    origin = synth.surf_volume(64, vs, 0.6)
+    cfg = capi.make_config(dims, vs, origin)
+    scene = synth.SurfScene(dims, vs, origin)
+    rng = np.random.default_rng(7)
+    ref_t, ref_w = oracle.init_grid(dims)
+    with capi.Volume(cfg) as vol:
+        for k in range(3):
+            c2w = scene.pose(k, n=3)
+            depth = scene.depth(c2w)
+            mask = np.zeros((480, 640), np.uint8)
+            y0, x0 = rng.integers(100, 200, 2)
+            mask[y0:y0 + 250, x0:x0 + 300] = 255  # MaskRCNN output format {0,255}
+            d_dev, m_dev = dev(cuda, depth), dev(cuda, mask)
+            vol.integrate_masked_device(d_dev.data_ptr(), m_dev.data_ptr(), c2w)
+            vol.sync()
+            masked = oracle.mask_depth(depth, mask)
+            oracle.integrate(cfg.cam_K, c2w, masked, dims, origin, vs, cfg.trunc_margin, ref_t, ref_w)
+        got_t, got_w = vol.download()
+    assert ref_w.max() > 0
+    assert_parity(got_t, got_w, ref_t, ref_w)
+
+
+def test_edge_inputs(cuda, oracle):
+    """All-invalid depth, camera behind the volume, volume outside the image: nothing changes."""
+    dims, vs = (32, 32, 32), 0.01
+    origin = synth.surf_volume(32, vs, 1.0)
+    cfg = capi.make_config(dims, vs, origin)
+    with capi.Volume(cfg) as vol:
+        zero = dev(cuda, np.zeros((480, 640), np.float32))
+        far = dev(cuda, np.full((480, 640), 6.0001, np.float32))
+        ok = dev(cuda, np.full((480, 640), 2.0, np.float32))
+        vol.integrate_device(zero.data_ptr(), synth.identity_pose())
+        vol.integrate_device(far.data_ptr(), synth.identity_pose())
+        behind = synth.make_pose(synth.rot_y(np.pi), [0, 0, 0])  # looking away
+        vol.integrate_device(ok.data_ptr(), behind)
+        aside = synth.make_pose(np.eye(3), [50.0, 0, 0])  # volume far outside the frustum
+        vol.integrate_device(ok.data_ptr(), aside)
+        t, w = vol.download()
+        assert np.all(t == 1.0) and np.all(w == 0.0)
+        # exactly 6.0 m is still valid (ref: `depth_val > 6` rejects, src/tsdf.cu:46)
+        six = dev(cuda, np.full((480, 640), 6.0, np.float32))
+        vol.integrate_device(six.data_ptr(), synth.identity_pose())
+        t, w = vol.download()
+        rt, rw = oracle.init_grid(dims)
+        oracle.integrate(cfg.cam_K, synth.identity_pose(), np.full((480, 640), 6.0, np.float32), dims,
+                         origin, vs, cfg.trunc_margin, rt, rw)
+        assert rw.sum() > 0
+        assert_parity(t, w, rt, rw)
+        vol.reset()
+        t, w = vol.download()
+        assert np.all(t == 1.0) and np.all(w == 0.0)
+
+
+def test_singular_base_pose_is_ignored_like_the_reference(cuda, oracle):
+    """ref: src/tsdf.cu:74 ignores invert_matrix's false -> base2world_inv stays zero."""
+    dims, vs = (16, 16, 16), 0.02
+    origin = synth.surf_volume(16, vs, 1.0)
+    cfg = capi.make_config(dims, vs, origin, base2world=np.zeros(16, np.float32))
+    with capi.Volume(cfg) as vol:
+        d = dev(cuda, np.full((480, 640), 2.0, np.float32))
+        vol.integrate_device(d.data_ptr(), synth.identity_pose())
+        c2b = vol.last_cam2base()
+        assert np.array_equal(c2b, oracle.cam2base(np.zeros(16, np.float32), synth.identity_pose()))
+        t, w = vol.download()
+        rt, rw = oracle.init_grid(dims)
+        oracle.integrate(cfg.cam_K, c2b, np.full((480, 640), 2.0, np.float32), dims, origin, vs,
+                         cfg.trunc_margin, rt, rw)
+        assert_parity(t, w, rt, rw)
+
+
+def test_surface_and_files_match_oracle(cuda, oracle, tmp_path):
+    """Device compaction == the reference's host scan; .ply/.bin byte-identical to the oracle's."""
+    dims, vs = (72, 56, 40), 0.01
+    origin = synth.surf_volume(72, vs, 0.6)
+    cfg = capi.make_config(dims, vs, origin, vol_id=3)
+    scene = synth.SurfScene(dims, vs, origin)
+    ref_t, ref_w = oracle.init_grid(dims)
+    with capi.Volume(cfg) as vol:
+        for k in range(4):
+            c2w = scene.pose(k, n=4)
+            depth = scene.depth(c2w)
+            vol.integrate(depth, c2w)
+            oracle.integrate(cfg.cam_K, c2w, depth, dims, origin, vs, cfg.trunc_margin, ref_t, ref_w)
+        # make some TSDF values exactly zero so the |tsdf| != 0 half of the test matters
+        t, w = vol.download()
+        idx = np.flatnonzero(w > 0)[::97]
+        t[idx] = 0.0
+        ref_t[idx] = 0.0
+        vol.upload(t, w)
+        want = oracle.surface_points(ref_t, ref_w, dims, vs, origin)
+        assert 0 < len(want) < t.size
+        assert vol.count_surface() == len(want)
+        got = vol.extract_surface()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        vol.save_ply(str(tmp_path / "a.ply"))
+        vol.save_bin(str(tmp_path / "a.bin"))
+    oracle.save_ply(str(tmp_path / "b.ply"), ref_t, ref_w, dims, vs, origin)
+    oracle.save_bin(str(tmp_path / "b.bin"), ref_t, dims, origin, vs, cfg.trunc_margin)
+    assert (tmp_path / "a.ply").read_bytes() == (tmp_path / "b.ply").read_bytes()
+    assert (tmp_path / "a.bin").read_bytes() == (tmp_path / "b.bin").read_bytes()
+
+
+def test_full_size_512_sfull(cuda, oracle):
+    """BASELINE config[1]: 512^3 @ 5 mm, full-coverage input.  Checked against the oracle on a
+    z-slab sample and through size-independent properties on the whole grid."""
+    D, vs = 512, 0.005
+    origin = synth.sfull_volume(D, vs)
+    cfg = capi.make_config((D, D, D), vs, origin)
+    depth = synth.sfull_depth()
+    frames = 3
+    with capi.Volume(cfg) as vol:
+        d_dev = dev(cuda, depth)
+        for k in range(frames):
+            vol.integrate_device(d_dev.data_ptr(), synth.sfull_pose(k))
+        t, w = vol.download()
+    # property: every voxel updated every frame, and the mean of dist = 1 stays exactly 1
+    assert np.all(w == float(frames)), "S-full must update every voxel every frame (N_upd == N)"
+    assert np.all(t == 1.0)
+    # oracle on three slabs (first, middle, last 8 slices)
+    for zb in (0, 252, 504):
+        st, sw = oracle.init_grid((D, D, D), zb, zb + 8)
+        n = 0
+        for k in range(frames):
+            n += oracle.integrate(cfg.cam_K, synth.sfull_pose(k), depth, (D, D, D), origin, vs,
+                                  cfg.trunc_margin, st, sw, z_begin=zb, z_end=zb + 8)
+        assert n == frames * 8 * D * D
+        lo, hi = zb * D * D, (zb + 8) * D * D
+        assert_parity(t[lo:hi], w[lo:hi], st, sw)
+
+
+def test_full_size_512_surface_scene(cuda, oracle):
+    """512^3 with a real surface: whole-grid bit parity against the (multi-threaded) oracle."""
+    D, vs = 512, 0.005
+    origin = synth.surf_volume(D, vs, 1.0)
+    cfg = capi.make_config((D, D, D), vs, origin)
+    scene = synth.SurfScene((D, D, D), vs, origin)
+    ref_t, ref_w = oracle.init_grid((D, D, D))
+    with capi.Volume(cfg) as vol:
+        for k in range(2):
+            c2w = scene.pose(k * 9, n=64)
+            depth = scene.depth(c2w, quantize=True)
+            vol.integrate(depth, c2w)
+            oracle.integrate(cfg.cam_K, c2w, depth, (D, D, D), origin, vs, cfg.trunc_margin, ref_t, ref_w)
+        got_t, got_w = vol.download()
+    frac = float(np.count_nonzero(ref_w)) / ref_w.size
+    assert 0.05 < frac < 0.95, f"updated fraction {frac}: scene should mix updated and skipped voxels"
+    assert_parity(got_t, got_w, ref_t, ref_w)
