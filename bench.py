@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""bench.py -- Mvoxels/s of the HIP TSDF Integrate path (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--grid 512] [--workload sfull|ssurf]
+
+One "step" = one Integrate of one 640x480 depth frame into the whole grid.  At N = 1 the
+workload is BASELINE.json configs[1]: 512^3 @ 5 mm, synthetic depth + pose stream (S-full,
+SURVEY.md section 8d: every voxel updated every frame, so algorithmic bytes = 16 B x voxels).  For
+N > 1 the SAME grid is cut into N z-slabs, one per rank (strong scaling, no data-path
+collective: voxels are independent); launch with torch.distributed.run as the driver does.
+The depth frame is resident in HBM before the timed region.  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--grid", type=int, default=512, help="grid edge in voxels (512 or 1024)")
+    ap.add_argument("--workload", default="sfull", choices=["sfull", "ssurf"])
+    ap.add_argument("--variant", type=int, default=0, help="kernel variant (see DESIGN.md)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, dims, vs, origin, cfg, depth, poses, n_upd_expected_per_slice):
+    """Time the CPU oracle (and the reference's own kernel body when oracle/_ref was built) on a
+    bounded z-slab sample of the same workload, all host threads.  Checker code: it is
+    measured here as the baseline, never used to produce the GPU result."""
+    from oracle.oracle import Oracle, Ref
+    orc = Oracle()
+    D = dims[0]
+    nz = min(D, 64)                      # sample: the middle nz slices of the grid
+    zb = (D - nz) // 2
+    threads = orc.max_threads()
+    t, w = orc.init_grid(dims, zb, zb + nz)
+    orc.integrate(cfg.cam_K, poses[0], depth, dims, origin, vs, cfg.trunc_margin, t, w, z_begin=zb,
+                  z_end=zb + nz, threads=threads)  # warm-up: page in the slab
+    frames, t0, n_upd = 0, time.perf_counter(), 0
+    while True:
+        n_upd += orc.integrate(cfg.cam_K, poses[(frames + 1) % len(poses)], depth, dims, origin, vs,
+                               cfg.trunc_margin, t, w, z_begin=zb, z_end=zb + nz, threads=threads)
+        frames += 1
+        el = time.perf_counter() - t0
+        if el > args.cpu_seconds or frames >= 200:
+            break
+    out = {"value": round(nz * D * D * frames / el / 1e6, 1), "unit": "Mvoxels/s", "cores": threads,
+           "kind": "port",
+           "sample": f"oracle/tsdf_oracle.c (OpenMP over z), {frames} frames of the same workload into "
+                     f"z-slab [{zb},{zb + nz}) of the {D}^3 grid, {el:.1f} s"}
+    if n_upd_expected_per_slice is not None:
+        assert n_upd == frames * nz * n_upd_expected_per_slice, "S-full must update every voxel (N_upd == N)"
+    ref = None
+    if Ref.available() and D <= 1024:
+        # the reference body has no slab form: give it a grid that IS the slab (origin shifted in z
+        # on the host; timing only, values are not compared here)
+        r = Ref()
+        rd = (D, D, nz)
+        ro = np.array([origin[0], origin[1], origin[2] + zb * vs], np.float32)
+        t2, w2 = orc.init_grid(rd)
+        r.integrate(cfg.cam_K, poses[0], depth, rd, ro, vs, cfg.trunc_margin, t2, w2, threads=threads)
+        f2, t0 = 0, time.perf_counter()
+        while True:
+            r.integrate(cfg.cam_K, poses[(f2 + 1) % len(poses)], depth, rd, ro, vs, cfg.trunc_margin, t2, w2,
+                        threads=threads)
+            f2 += 1
+            el2 = time.perf_counter() - t0
+            if el2 > args.cpu_seconds / 2 or f2 >= 200:
+                break
+        ref = {"value": round(nz * D * D * f2 / el2 / 1e6, 1), "unit": "Mvoxels/s", "cores": threads,
+               "kind": "reference",
+               "sample": f"GpuIntegrate body of the reference (src/tsdf.cu:15-60) built for the host by "
+                         f"oracle/Makefile, {f2} frames into a {D}x{D}x{nz} grid, {el2:.1f} s"}
+    return out, ref
+
+
+def main():
+    args = parse()
+    import torch
+    from semantic_slam_amd import capi, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs: python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    D = args.grid
+    vs = {512: 0.005, 1024: 0.002}.get(D, 2.56 / D)
+    dims = (D, D, D)
+    if args.workload == "sfull":
+        origin = synth.sfull_volume(D, vs)
+        depth = synth.sfull_depth()
+        n_pose = 64
+        poses = np.stack([synth.sfull_pose(k) for k in range(n_pose)])
+    else:
+        origin = synth.surf_volume(D, vs, 1.0)
+        scene = synth.SurfScene(dims, vs, origin)
+        n_pose = 64
+        poses = np.stack([scene.pose(k, n_pose) for k in range(n_pose)])
+        depth = scene.depth(poses[0], quantize=True)  # one resident frame, orbiting camera
+
+    # z-slab of this rank (ref layout is z-major, so a slab is one contiguous range)
+    zb, ze = rank * D // world, (rank + 1) * D // world
+    cfg = capi.make_config(dims, vs, origin, z_begin=zb, z_end=ze, device=local_rank)
+    vol = capi.Volume(cfg)
+    vol.set_kernel_variant(args.variant)
+    d_dev = torch.from_numpy(depth).cuda()
+
+    def pose_block(start, n):
+        return np.stack([poses[(start + i) % n_pose] for i in range(n)])
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        vol.integrate_sequence_timed(d_dev.data_ptr(), pose_block(0, args.warmup))
+    fence()
+    t0 = time.perf_counter()
+    # exactly K steps, queued back to back on the handle's stream, HIP events around them
+    kernel_ms_total = vol.integrate_sequence_timed(d_dev.data_ptr(), pose_block(args.warmup, args.steps))
+    fence()
+    wall = time.perf_counter() - t0
+
+    tt = torch.tensor([wall, kernel_ms_total], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    wall, kernel_ms_total = float(tt[0]), float(tt[1])
+
+    # --- what was integrated: count updates on this rank's slab ------------------------------
+    t_host, w_host = vol.download()
+    n_frames = args.warmup + args.steps
+    n_slab = vol.n_voxels
+    upd_total = float(w_host.astype(np.float64).sum())  # each update adds exactly 1 to one weight
+    if args.workload == "sfull":
+        assert w_host.min() == w_host.max() == float(n_frames), "S-full: every voxel every frame"
+        assert np.all(t_host == 1.0)
+    n_upd_per_launch = upd_total / n_frames
+    del t_host, w_host
+
+    # --- roofline of the dominant kernel (integrate_tile) on this rank -------------------------
+    # Bytes the frame must move (DESIGN.md "Bytes model"): per updated voxel 4 B TSDF read + 4 B
+    # weight read + 4 B weight write, plus 4 B TSDF write only where the value changes (the kernel
+    # does not store unchanged TSDF rows), plus one pass over the depth frame and the parameters.
+    # SURVEY.md section 8(d) counted 16 B for every updated voxel; that figure is reported beside it.
+    H, W = depth.shape
+    if args.workload == "sfull" or args.variant in (2, 16, 17, 20, 21, 24, 25):
+        n_tsdf_written = 0.0 if (args.workload == "sfull" and args.variant not in (2, 16, 17, 20, 21, 24, 25)) \
+            else n_upd_per_launch
+        tsdf_write_note = "exact"
+    else:
+        n_tsdf_written = n_upd_per_launch   # upper bound: changed voxels are not counted on the device
+        tsdf_write_note = "upper bound (every updated voxel counted as changed)"
+    bytes_per_launch = 12.0 * n_upd_per_launch + 4.0 * n_tsdf_written + 4.0 * H * W + 100.0
+    bytes_survey = 16.0 * n_upd_per_launch + 4.0 * H * W + 100.0
+    kernel_ms = kernel_ms_total / args.steps
+    achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+    achieved_survey = bytes_survey / (kernel_ms * 1e-3) / 1e9
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.isfile(tpath):
+        try:
+            rec = json.load(open(tpath))
+            key = f"{args.workload}_{D}_slab{ze - zb}"
+            if key in rec:
+                traffic = rec[key]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
+
+    line = {
+        "metric": f"Mvoxels/sec integrated, {D}^3 grid @ 640x480 depth; achieved HBM GB/s %peak",
+        "value": round(D ** 3 * args.steps / wall / 1e6, 1),
+        "unit": "Mvoxels/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(wall / args.steps * 1e3, 5),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{args.workload} {D}^3 @ {vs * 1000:g} mm, 640x480 depth resident in HBM, "
+                               f"{'every voxel updated every frame' if args.workload == 'sfull' else 'sphere+wall orbit'}",
+                   "grid": [D, D, D], "voxel_size_m": vs, "image": [H, W],
+                   "partition": f"{world} z-slab(s) of {ze - zb} slices, one per GPU",
+                   "kernel_variant": args.variant},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "kernel": "tsdfk::integrate_tile<2,true,true,false>" if args.variant == 0 else f"variant {args.variant}",
+                     "kernel_ms": round(kernel_ms, 5),
+                     "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                     "voxels_updated_per_launch": int(n_upd_per_launch),
+                     "tsdf_values_written_per_launch": int(n_tsdf_written),
+                     "tsdf_write_count": tsdf_write_note,
+                     "bytes_model": "12 B per updated voxel + 4 B per changed TSDF value + 4*H*W + 100",
+                     "survey_16B_model": {"bytes_per_launch": int(bytes_survey), "achieved": round(achieved_survey, 1),
+                                          "frac": round(achieved_survey / HBM_PEAK_GBS, 4)},
+                     "note": "per-rank slab launch; average over the timed steps from HIP events on the launch stream"},
+    }
+    if not args.no_cpu_baseline and world == 1:
+        per_slice = D * D if args.workload == "sfull" else None
+        base, ref = cpu_baseline(args, dims, vs, origin, cfg, depth, poses, per_slice)
+        line["cpu_baseline"] = base
+        if ref is not None:
+            line["cpu_reference"] = ref
+    print(json.dumps(line))
+    sys.stdout.flush()
+    vol.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

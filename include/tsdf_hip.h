@@ -114,6 +114,14 @@ int tsdf_sync(tsdf_volume *vol);
  */
 int tsdf_download(tsdf_volume *vol, float *tsdf_host, float *weight_host);
 
+/*
+ * Copy n_slices whole z-slices starting at slab-local slice z_local into tsdf_dst / weight_dst
+ * (either may be NULL), each n_slices*dim_y*dim_x floats.  The destinations may be host or
+ * device addresses (the copy kind is inferred), so a one-slice halo can go straight into a
+ * communication buffer in HBM.  Synchronous with respect to the handle's stream.
+ */
+int tsdf_copy_slices(tsdf_volume *vol, int32_t z_local, int32_t n_slices, void *tsdf_dst, void *weight_dst);
+
 /* Restore a slab from host arrays (resume from a saved state).  Synchronous. */
 int tsdf_upload(tsdf_volume *vol, const float *tsdf_host, const float *weight_host);
 
@@ -168,6 +176,12 @@ int tsdf_save_bin(tsdf_volume *vol, const char *path);
  */
 int tsdf_integrate_sequence_timed(tsdf_volume *vol, const float *depth_dev, const float *cam2world,
                                   int32_t n_frames, float *elapsed_ms);
+
+/*
+ * Ceiling probe: n_iters passes of a bare 16 B/voxel read-modify-write stream over the slab
+ * (values unchanged), timed with HIP events.  non_temporal selects nt loads/stores.
+ */
+int tsdf_probe_stream(tsdf_volume *vol, int32_t non_temporal, int32_t n_iters, float *elapsed_ms);
 
 /* Select the Integrate kernel variant (0 = default; others are listed in DESIGN.md). */
 int tsdf_set_kernel_variant(tsdf_volume *vol, int32_t variant);

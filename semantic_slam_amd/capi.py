@@ -16,10 +16,10 @@ LIB_PATH = os.path.join(_PKG, "libtsdf_hip.so")
 ABI_SYMBOLS = [
     "tsdf_config_default", "tsdf_create", "tsdf_destroy", "tsdf_reset", "tsdf_integrate",
     "tsdf_integrate_device", "tsdf_integrate_cam2base", "tsdf_integrate_masked_device",
-    "tsdf_sync", "tsdf_download", "tsdf_upload", "tsdf_device_ptrs", "tsdf_slab_voxels",
+    "tsdf_sync", "tsdf_download", "tsdf_copy_slices", "tsdf_upload", "tsdf_device_ptrs", "tsdf_slab_voxels",
     "tsdf_get_config", "tsdf_last_cam2base", "tsdf_set_stream", "tsdf_get_stream",
     "tsdf_count_surface", "tsdf_extract_surface", "tsdf_save_ply", "tsdf_save_bin",
-    "tsdf_integrate_sequence_timed", "tsdf_set_kernel_variant", "tsdf_last_error",
+    "tsdf_integrate_sequence_timed", "tsdf_probe_stream", "tsdf_set_kernel_variant", "tsdf_last_error",
     "tsdf_version", "tsdf_multiply_matrix", "tsdf_invert_matrix",
 ]
 
@@ -64,6 +64,7 @@ def load():
     L.tsdf_sync.argtypes = [vp]
     L.tsdf_download.argtypes = [vp, vp, vp]
     L.tsdf_upload.argtypes = [vp, vp, vp]
+    L.tsdf_copy_slices.argtypes = [vp, C.c_int32, C.c_int32, vp, vp]
     L.tsdf_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     L.tsdf_slab_voxels.argtypes = [vp]
     L.tsdf_slab_voxels.restype = C.c_int64
@@ -76,6 +77,7 @@ def load():
     L.tsdf_save_ply.argtypes = [vp, C.c_char_p, C.c_float]
     L.tsdf_save_bin.argtypes = [vp, C.c_char_p]
     L.tsdf_integrate_sequence_timed.argtypes = [vp, vp, vp, C.c_int32, f32p]
+    L.tsdf_probe_stream.argtypes = [vp, C.c_int32, C.c_int32, f32p]
     L.tsdf_set_kernel_variant.argtypes = [vp, C.c_int32]
     L.tsdf_last_error.restype = C.c_char_p
     L.tsdf_version.restype = C.c_char_p
@@ -211,6 +213,12 @@ class Volume:
               "tsdf_integrate_sequence_timed")
         return ms.value
 
+    def probe_stream(self, non_temporal=False, iters=20):
+        """Bare RMW stream over the slab (ceiling probe); returns milliseconds per pass."""
+        ms = C.c_float()
+        check(self.lib.tsdf_probe_stream(self._h, int(non_temporal), iters, C.byref(ms)), "tsdf_probe_stream")
+        return ms.value / iters
+
     def last_cam2base(self):
         out = np.empty(16, np.float32)
         check(self.lib.tsdf_last_cam2base(self._h, out.ctypes.data), "tsdf_last_cam2base")
@@ -228,6 +236,17 @@ class Volume:
         t, w = np.empty(n, np.float32), np.empty(n, np.float32)
         check(self.lib.tsdf_download(self._h, t.ctypes.data, w.ctypes.data), "tsdf_download")
         return t, w
+
+    def copy_slices(self, z_local, n_slices):
+        """Host copies of n_slices whole z-slices starting at slab-local z_local."""
+        n = n_slices * self.cfg.dim_x * self.cfg.dim_y
+        t, w = np.empty(n, np.float32), np.empty(n, np.float32)
+        check(self.lib.tsdf_copy_slices(self._h, z_local, n_slices, t.ctypes.data, w.ctypes.data), "tsdf_copy_slices")
+        return t, w
+
+    def copy_slices_to_device(self, z_local, n_slices, tsdf_ptr, weight_ptr):
+        """Same, into device buffers (e.g. an RCCL send buffer): no host hop."""
+        check(self.lib.tsdf_copy_slices(self._h, z_local, n_slices, tsdf_ptr, weight_ptr), "tsdf_copy_slices")
 
     def upload(self, tsdf, weight):
         t, w = _f32(tsdf, self.n_voxels), _f32(weight, self.n_voxels)

@@ -104,8 +104,23 @@ tsdfk::IntegrateParams make_params(const tsdf_volume *v, const float *depth_dev,
     return p;
 }
 
-// Queue one Integrate launch.  Shapes are validated at tsdf_create, so the grid below covers
-// exactly the slab and every access stays inside the two allocations.
+// Kernel variants (tsdf_set_kernel_variant):
+//   0        default: integrate_tile<2, elide, nt> when dim_x % 4 == 0, else the scalar kernel
+//   1        scalar kernel integrate_rows<1> (any dim_x)
+//   2        first version integrate_rows<4> (one row per wavefront, no elision)
+//   16 + c   experiments: c = (rsel << 2) | (elide << 1) | nt, R = 1, 2, 4 for rsel = 0, 1, 2
+constexpr int kDefaultTile = 16 + ((1 << 2) | (1 << 1) | 1);  // R = 2, elide, non-temporal (fastest measured)
+
+template <int R, bool ELIDE, bool NT, bool MASKED>
+void launch_tile(const tsdf_volume *v, const tsdfk::IntegrateParams &p)
+{
+    dim3 block(64, 4, 1);
+    dim3 grid((p.xgroups + 63) / 64, (p.dim_y + 4 * R - 1) / (4 * R), p.nz);
+    hipLaunchKernelGGL((tsdfk::integrate_tile<R, ELIDE, NT, MASKED>), grid, block, 0, v->stream, p);
+}
+
+// Queue one Integrate launch.  Shapes are validated at tsdf_create, so the grid covers exactly
+// the slab and every access stays inside the two allocations.
 int launch_integrate(tsdf_volume *v, const float *depth_dev, const uint8_t *mask_dev,
                      const float *c2b)
 {
@@ -113,17 +128,35 @@ int launch_integrate(tsdf_volume *v, const float *depth_dev, const uint8_t *mask
     const int nz = c.z_end - c.z_begin;
     if (nz == 0) return TSDF_OK;  // empty slab: nothing to do
     std::memcpy(v->last_cam2base, c2b, sizeof v->last_cam2base);
-    const bool vec4 = (c.dim_x % 4 == 0) && v->variant != 1;
-    const int vx = vec4 ? 4 : 1;
+    int variant = v->variant;
+    if (variant == 0) variant = kDefaultTile;
+    if (c.dim_x % 4 != 0) variant = 1;  // rows are not 16-byte aligned: scalar kernel
+    const int vx = variant == 1 ? 1 : 4;
     tsdfk::IntegrateParams p = make_params(v, depth_dev, mask_dev, c2b, vx);
-    dim3 block(64, 4, 1);
-    dim3 grid((p.xgroups + 63) / 64, (c.dim_y + 3) / 4, nz);
-    if (vec4) {
-        if (mask_dev) hipLaunchKernelGGL((tsdfk::integrate_rows<4, true>), grid, block, 0, v->stream, p);
-        else hipLaunchKernelGGL((tsdfk::integrate_rows<4, false>), grid, block, 0, v->stream, p);
+    if (variant == 1 || variant == 2) {
+        dim3 block(64, 4, 1);
+        dim3 grid((p.xgroups + 63) / 64, (c.dim_y + 3) / 4, nz);
+        if (variant == 2) {
+            if (mask_dev) hipLaunchKernelGGL((tsdfk::integrate_rows<4, true>), grid, block, 0, v->stream, p);
+            else hipLaunchKernelGGL((tsdfk::integrate_rows<4, false>), grid, block, 0, v->stream, p);
+        } else {
+            if (mask_dev) hipLaunchKernelGGL((tsdfk::integrate_rows<1, true>), grid, block, 0, v->stream, p);
+            else hipLaunchKernelGGL((tsdfk::integrate_rows<1, false>), grid, block, 0, v->stream, p);
+        }
+    } else if (mask_dev) {
+        launch_tile<2, true, true, true>(v, p);  // masked fusion uses the default configuration
     } else {
-        if (mask_dev) hipLaunchKernelGGL((tsdfk::integrate_rows<1, true>), grid, block, 0, v->stream, p);
-        else hipLaunchKernelGGL((tsdfk::integrate_rows<1, false>), grid, block, 0, v->stream, p);
+        switch (variant - 16) {
+#define TILE_CASE(code, R, E, N) case code: launch_tile<R, E, N, false>(v, p); break;
+            TILE_CASE(0, 1, false, false) TILE_CASE(1, 1, false, true)
+            TILE_CASE(2, 1, true, false)  TILE_CASE(3, 1, true, true)
+            TILE_CASE(4, 2, false, false) TILE_CASE(5, 2, false, true)
+            TILE_CASE(6, 2, true, false)  TILE_CASE(7, 2, true, true)
+            TILE_CASE(8, 4, false, false) TILE_CASE(9, 4, false, true)
+            TILE_CASE(10, 4, true, false) TILE_CASE(11, 4, true, true)
+#undef TILE_CASE
+            default: return fail(TSDF_ERR_INVALID, "unknown kernel variant %d", variant);
+        }
     }
     HIP_TRY(hipGetLastError());
     return TSDF_OK;
@@ -348,6 +381,23 @@ int tsdf_download(tsdf_volume *v, float *tsdf_host, float *weight_host)
     return TSDF_OK;
 }
 
+int tsdf_copy_slices(tsdf_volume *v, int32_t z_local, int32_t n_slices, void *tsdf_dst, void *weight_dst)
+{
+    if (!v) return fail(TSDF_ERR_INVALID, "tsdf_copy_slices: NULL handle");
+    const int nz = v->cfg.z_end - v->cfg.z_begin;
+    if (z_local < 0 || n_slices < 0 || z_local + n_slices > nz)
+        return fail(TSDF_ERR_INVALID, "tsdf_copy_slices: slices [%d,%d) outside the slab's %d", z_local, z_local + n_slices, nz);
+    int rc = bind_device(v);
+    if (rc) return rc;
+    const size_t slice = (size_t)v->cfg.dim_x * v->cfg.dim_y;
+    const size_t bytes = slice * (size_t)n_slices * sizeof(float);
+    if (bytes == 0) return TSDF_OK;
+    if (tsdf_dst) HIP_TRY(hipMemcpyAsync(tsdf_dst, v->d_tsdf + slice * z_local, bytes, hipMemcpyDefault, v->stream));
+    if (weight_dst) HIP_TRY(hipMemcpyAsync(weight_dst, v->d_weight + slice * z_local, bytes, hipMemcpyDefault, v->stream));
+    HIP_TRY(hipStreamSynchronize(v->stream));
+    return TSDF_OK;
+}
+
 int tsdf_upload(tsdf_volume *v, const float *tsdf_host, const float *weight_host)
 {
     if (!v) return fail(TSDF_ERR_INVALID, "tsdf_upload: NULL handle");
@@ -405,8 +455,37 @@ int tsdf_get_stream(tsdf_volume *v, void **hip_stream)
 int tsdf_set_kernel_variant(tsdf_volume *v, int32_t variant)
 {
     if (!v) return fail(TSDF_ERR_INVALID, "tsdf_set_kernel_variant: NULL handle");
-    if (variant < 0 || variant > 1) return fail(TSDF_ERR_INVALID, "tsdf_set_kernel_variant: unknown variant %d", variant);
+    if (!(variant >= 0 && variant <= 2) && !(variant >= 16 && variant < 28))
+        return fail(TSDF_ERR_INVALID, "tsdf_set_kernel_variant: unknown variant %d", variant);
     v->variant = variant;
+    return TSDF_OK;
+}
+
+int tsdf_probe_stream(tsdf_volume *v, int32_t non_temporal, int32_t n_iters, float *elapsed_ms)
+{
+    if (!v || n_iters <= 0 || !elapsed_ms) return fail(TSDF_ERR_INVALID, "tsdf_probe_stream: bad argument");
+    int rc = bind_device(v);
+    if (rc) return rc;
+    if (v->n_vox % 4 != 0 || v->n_vox == 0) return fail(TSDF_ERR_INVALID, "tsdf_probe_stream: slab voxels must be a positive multiple of 4");
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    const size_t nq = (size_t)v->n_vox / 4;
+    const int blocks = (int)std::min<size_t>((nq + 255) / 256, (size_t)256 * 8);
+    HIP_TRY(hipEventRecord(e0, v->stream));
+    for (int i = 0; i < n_iters; ++i) {
+        if (non_temporal) hipLaunchKernelGGL(tsdfk::stream_rmw<true>, dim3(blocks), dim3(256), 0, v->stream, v->d_tsdf, v->d_weight, nq, 1.0f, 0.0f);
+        else hipLaunchKernelGGL(tsdfk::stream_rmw<false>, dim3(blocks), dim3(256), 0, v->stream, v->d_tsdf, v->d_weight, nq, 1.0f, 0.0f);
+    }
+    hipError_t er = hipEventRecord(e1, v->stream);
+    hipError_t es = hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipError_t et = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (er != hipSuccess || es != hipSuccess || et != hipSuccess)
+        return fail(TSDF_ERR_HIP, "tsdf_probe_stream: event timing failed");
+    *elapsed_ms = ms;
     return TSDF_OK;
 }
 

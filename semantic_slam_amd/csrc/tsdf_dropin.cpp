@@ -1,0 +1,169 @@
+// tsdf_dropin.cpp -- the C++ host side above the C ABI: class TSDF and class TSDFfusion with the
+// reference's public surface (ref: include/tsdf.hpp:22-43, include/TSDFfusion.hpp:25-49),
+// forwarding to libtsdf_hip.so.  Built into libtsdf_dropin.so with plain g++.
+#include "tsdf.hpp"
+#include "TSDFfusion.hpp"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <stdexcept>
+
+namespace {
+bool g_throw = false;
+const long long kEagerMirrorLimit = 1LL << 28;  // host mirrors above 256 Mi voxels are allocated on Download()
+}
+
+void TSDF::ThrowOnError(bool on) { g_throw = on; }
+
+// ref: src/tsdf.cu:405-420 -- the reference prints and exits; opt-in exceptions for library use
+void TSDF::fail(const char *what, int line) const
+{
+	std::string msg = std::string(what) + ": " + tsdf_last_error();
+	if (g_throw) throw std::runtime_error(msg);
+	std::cerr << "TSDF failure at LINE " << line << ": " << msg << std::endl;
+	std::cerr << "FatalError. Program Terminated." << std::endl;
+	std::exit(EXIT_FAILURE);
+}
+
+TSDF::TSDF(int h, int w, int MOid, std::vector<float> base2world_, std::vector<float> origin)
+	: voxel_grid_TSDF(NULL), voxel_grid_weight(NULL), vol_(NULL), save_on_destroy_(true)
+{
+	tsdf_config_default(&cfg_, h, w);  // 200^3 @ 4 mm, trunc 20 mm, TUM K (ref: include/tsdf.hpp:63-67,96)
+	cfg_.id = MOid;
+	for (size_t i = 0; i < 3 && i < origin.size(); ++i) cfg_.origin[i] = origin[i];           // ref: src/tsdf.cu:66-68
+	for (size_t i = 0; i < 16 && i < base2world_.size(); ++i) cfg_.base2world[i] = base2world_[i];  // ref: :72
+	init();
+}
+
+TSDF::TSDF(const tsdf_config &cfg)
+	: voxel_grid_TSDF(NULL), voxel_grid_weight(NULL), cfg_(cfg), vol_(NULL), save_on_destroy_(true)
+{
+	init();
+}
+
+void TSDF::init()
+{
+	if (tsdf_create(&cfg_, &vol_) != TSDF_OK) fail("tsdf_create", __LINE__);
+	const long long n = tsdf_slab_voxels(vol_);
+	if (n <= kEagerMirrorLimit) {
+		// ref: src/tsdf.cu:77-81 -- host mirrors exist from construction, TSDF = 1, weight = 0
+		voxel_grid_TSDF = new float[n > 0 ? n : 1];
+		voxel_grid_weight = new float[n > 0 ? n : 1];
+		for (long long i = 0; i < n; ++i) voxel_grid_TSDF[i] = 1.0f;
+		std::memset(voxel_grid_weight, 0, sizeof(float) * (size_t)n);
+	}
+}
+
+void TSDF::Integrate(float *depth_im, std::vector<float> cam2world_vec)
+{
+	float cam2world[16] = {0};
+	for (size_t i = 0; i < 16 && i < cam2world_vec.size(); ++i) cam2world[i] = cam2world_vec[i];  // ref: src/tsdf.cu:139
+	if (tsdf_integrate(vol_, depth_im, cam2world) != TSDF_OK) fail("tsdf_integrate", __LINE__);
+}
+
+void TSDF::Sync()
+{
+	if (tsdf_sync(vol_) != TSDF_OK) fail("tsdf_sync", __LINE__);
+}
+
+void TSDF::Download()
+{
+	const long long n = tsdf_slab_voxels(vol_);
+	if (!voxel_grid_TSDF) voxel_grid_TSDF = new float[n > 0 ? n : 1];
+	if (!voxel_grid_weight) voxel_grid_weight = new float[n > 0 ? n : 1];
+	if (tsdf_download(vol_, voxel_grid_TSDF, voxel_grid_weight) != TSDF_OK) fail("tsdf_download", __LINE__);
+}
+
+TSDF::~TSDF()
+{
+	if (vol_) {
+		if (save_on_destroy_) {
+			Download();  // ref: src/tsdf.cu:101-104
+			// ref: src/tsdf.cu:109-112 -- surface points, weight threshold 0.9 (tsdf_thresh 1.2 is unused there)
+			std::string name = "tsdf" + std::to_string(cfg_.id) + ".ply";
+			if (tsdf_save_ply(vol_, name.c_str(), 0.9f) != TSDF_OK) fail("tsdf_save_ply", __LINE__);
+			name = "tsdf" + std::to_string(cfg_.id) + ".bin";  // ref: src/tsdf.cu:116-132
+			if (tsdf_save_bin(vol_, name.c_str()) != TSDF_OK) fail("tsdf_save_bin", __LINE__);
+		}
+		tsdf_destroy(vol_);
+		vol_ = NULL;
+	}
+	delete[] voxel_grid_TSDF;    // the reference leaks both mirrors and the device buffers
+	delete[] voxel_grid_weight;
+}
+
+// ------------------------------------------------------------------------------------------------
+// TSDFfusion
+// ------------------------------------------------------------------------------------------------
+TSDFfusion::TSDFfusion() : vol_(NULL)
+{
+	initialise();
+}
+
+void TSDFfusion::initialise()
+{
+	std::cout << " * Initialising TSDFfusion ... ";  // ref: src/TSDFfusion.cpp:44
+	tsdf_config cfg;
+	tsdf_config_default(&cfg, 480, 640);
+	// ref: src/TSDFfusion.py.in:19-29 -- bounds [0,10]^3, voxel 0.02 -> 500^3; K is the same TUM fr3 matrix
+	cfg.dim_x = cfg.dim_y = cfg.dim_z = 500;
+	cfg.z_begin = 0;
+	cfg.z_end = 500;
+	cfg.voxel_size = 0.02f;
+	cfg.trunc_margin = cfg.voxel_size * 5;
+	cfg.origin[0] = cfg.origin[1] = cfg.origin[2] = 0.0f;
+	if (tsdf_create(&cfg, &vol_) != TSDF_OK)
+		throw std::runtime_error(std::string("Could not create the TSDF volume: ") + tsdf_last_error());
+	std::memset(pose_, 0, sizeof pose_);
+	pose_[0] = pose_[5] = pose_[10] = pose_[15] = 1.0f;
+	std::cout << "Done !" << std::endl;
+}
+
+TSDFfusion::~TSDFfusion()
+{
+	if (vol_) tsdf_destroy(vol_);
+	std::cout << "TSDFfusion has been deleted." << std::endl;  // ref: src/TSDFfusion.cpp:36
+}
+
+void TSDFfusion::SetPose(const float cam2world[16]) { std::memcpy(pose_, cam2world, sizeof pose_); }
+
+void TSDFfusion::Integrate(const unsigned char *, const float *depth, int height, int width, const float cam2world[16])
+{
+	tsdf_config cfg;
+	tsdf_get_config(vol_, &cfg);
+	if (height != cfg.im_height || width != cfg.im_width)
+		throw std::runtime_error("TSDFfusion::Integrate: depth image must be 480x640");
+	if (tsdf_integrate(vol_, depth, cam2world) != TSDF_OK)
+		throw std::runtime_error(std::string("TSDFfusion::Integrate: ") + tsdf_last_error());
+}
+
+void TSDFfusion::Integrate(const unsigned char *rgb, const float *depth, int height, int width)
+{
+	Integrate(rgb, depth, height, width, pose_);
+}
+
+#ifdef TSDFFUSION_HAVE_OPENCV
+void TSDFfusion::Integrate(cv::Mat imRGB, cv::Mat imD)
+{
+	if (imD.type() != CV_32F || !imD.isContinuous())
+		throw std::runtime_error("TSDFfusion::Integrate: depth must be continuous CV_32F metres");
+	Integrate(imRGB.data, (const float *)imD.data, imD.rows, imD.cols, pose_);
+}
+
+void TSDFfusion::Integrate(cv::Mat imRGB, cv::Mat imD, cv::Mat cam2world)
+{
+	cv::Mat p;
+	cam2world.convertTo(p, CV_32F);
+	p = p.clone();
+	SetPose((const float *)p.data);
+	Integrate(imRGB, imD);
+}
+#endif
+
+void TSDFfusion::SavePointCloud(const std::string &file_name)
+{
+	if (tsdf_save_ply(vol_, file_name.c_str(), 0.9f) != TSDF_OK)
+		throw std::runtime_error(std::string("TSDFfusion::SavePointCloud: ") + tsdf_last_error());
+}

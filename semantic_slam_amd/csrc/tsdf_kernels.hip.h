@@ -144,6 +144,204 @@ __global__ __launch_bounds__(256) void integrate_rows(IntegrateParams p)
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// integrate_tile<R, ELIDE, NT, MASKED>: the tuned kernel.
+//
+// block = 64 x 4 threads; a lane owns a 4(x) x R(y) patch of one z slice, a wavefront
+// 256(x) x R(y).  grid = (ceil(xgroups/64), ceil(dim_y/(4R)), nz).  Needs dim_x % 4 == 0.
+//
+//  * the x-only products (rx0*dx, ry0*dx, rz0*dx) are computed once and shared by the R rows;
+//  * all 4R depth samples of a lane are gathered before any is used (branch-free geometry,
+//    rejected voxels read pixel 0), then all 2R volume quads are loaded together: two memory
+//    round trips per wavefront per R rows instead of two per row;
+//  * a wavefront with nothing to update leaves before touching the volume (__ballot);
+//  * ELIDE: arithmetic whose result is known exactly is skipped per wavefront --
+//      - diff >= trunc  =>  fmin(1, diff/trunc) == 1: no division unless some lane is inside
+//        the truncation band (correctly rounded a/b >= 1 whenever a >= b > 0);
+//      - tsdf*w + dist == w + 1 (free space: tsdf 1, dist 1)  =>  the quotient is exactly 1:
+//        no division unless some lane differs;
+//      - a row whose TSDF values all come out bit-identical to what was loaded is not stored
+//        (the weight always changes and is always stored).
+//    Every skipped value is the value the full computation would produce, bit for bit.
+//  * NT: volume loads/stores carry the non-temporal hint (each byte is touched once per frame).
+// ------------------------------------------------------------------------------------------
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <bool NT>
+__device__ __forceinline__ float4 vol_load(const float *p)
+{
+    if constexpr (NT) {
+        v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    } else {
+        return *reinterpret_cast<const float4 *>(p);
+    }
+}
+template <bool NT>
+__device__ __forceinline__ void vol_store(float *p, float4 v)
+{
+    if constexpr (NT) {
+        v4f q = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(q, reinterpret_cast<v4f *>(p));
+    } else {
+        *reinterpret_cast<float4 *>(p) = v;
+    }
+}
+
+template <int R, bool ELIDE, bool NT, bool MASKED>
+__global__ __launch_bounds__(256) void integrate_tile(IntegrateParams p)
+{
+    const int xg = blockIdx.x * 64 + threadIdx.x;
+    const int gy0 = (blockIdx.y * 4 + threadIdx.y) * R;
+    const int lz = blockIdx.z;
+    if (xg >= p.xgroups || gy0 >= p.dim_y) return;
+    const int gz = p.z_begin + lz;
+
+    // x-only and z-only terms (ref: src/tsdf.cu:27,29,33,35-38)
+    float ax[4], ay[4], az[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float bx = p.ox + (float)(xg * 4 + j) * p.vs;
+        float dx = bx - p.tx;
+        ax[j] = p.rx0 * dx; ay[j] = p.ry0 * dx; az[j] = p.rz0 * dx;
+    }
+    const float bz = p.oz + (float)gz * p.vs;
+    const float dz = bz - p.tz;
+    const float x2 = p.rx2 * dz, y2 = p.ry2 * dz, z2 = p.rz2 * dz;
+
+    // ---- phase 1: geometry of all 4R voxels, depth gathers issued back to back --------------
+    float pcz[R][4], dval[R][4];
+    bool geo[R][4];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int gy = gy0 + r;
+        const bool row_ok = gy < p.dim_y;
+        const float by = p.oy + (float)gy * p.vs;   // ref: src/tsdf.cu:28
+        const float dy = by - p.ty;
+        const float x1 = p.rx1 * dy, y1 = p.ry1 * dy, z1 = p.rz1 * dy;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float cx = ax[j] + x1 + x2;
+            const float cy = ay[j] + y1 + y2;
+            const float cz = az[j] + z1 + z2;
+            pcz[r][j] = cz;
+            // ref: src/tsdf.cu:39-43.  cz <= 0 is tested before the quotient is used, exactly
+            // as the reference's `continue`; the division itself is harmless for any cz.
+            const float pu = roundf(p.fx * (cx / cz) + p.cx);
+            const float pv = roundf(p.fy * (cy / cz) + p.cy);
+            const bool ok = row_ok && !(cz <= 0.0f) && pu >= 0.0f && pu < (float)p.W && pv >= 0.0f &&
+                            pv < (float)p.H;
+            geo[r][j] = ok;
+            const int pix = ok ? (int)pv * p.W + (int)pu : 0;
+            float d = p.depth[pix];
+            if (MASKED) d = d * (p.mask[pix] >= 128 ? 1.0f : 0.0f);  // ref: src/Engine.cpp:192-193
+            dval[r][j] = d;
+        }
+    }
+
+    // ---- phase 2: depth tests (ref: src/tsdf.cu:46-49) ------------------------------------
+    float diff[R][4];
+    bool upd[R][4], rowany[R];
+    bool any = false, band = false;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        rowany[r] = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d = dval[r][j];
+            const float df = d - pcz[r][j];
+            diff[r][j] = df;
+            const bool u = geo[r][j] && !(d <= 0.0f || d > p.max_depth) && !(df <= -p.trunc);
+            upd[r][j] = u;
+            rowany[r] |= u;
+            band |= u && !(df >= p.trunc);
+        }
+        any |= rowany[r];
+    }
+    if (__ballot(any) == 0ull) return;  // wavefront early-out: no volume traffic at all
+    if (!any) return;
+
+    // ---- phase 3: volume quads in, truncated distance ----------------------------------------
+    const size_t row0 = ((size_t)lz * p.dim_y + gy0) * (size_t)p.dim_x + (size_t)xg * 4;
+    float4 t4[R], w4[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        t4[r] = make_float4(1.f, 1.f, 1.f, 1.f);
+        w4[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rowany[r]) {
+            t4[r] = vol_load<NT>(p.tsdf + row0 + (size_t)r * p.dim_x);
+            w4[r] = vol_load<NT>(p.weight + row0 + (size_t)r * p.dim_x);
+        }
+    }
+    float dist[R][4];
+    if (!ELIDE || __ballot(band) != 0ull) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dist[r][j] = fminf(1.0f, diff[r][j] / p.trunc);  // ref: :53
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dist[r][j] = 1.0f;
+    }
+
+    // ---- phase 4: running weighted mean (ref: src/tsdf.cu:54-57), stores ----------------------
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float tv[4] = {t4[r].x, t4[r].y, t4[r].z, t4[r].w};
+        float wv[4] = {w4[r].x, w4[r].y, w4[r].z, w4[r].w};
+        float num[4], wn[4];
+        bool need = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            wn[j] = wv[j] + 1.0f;
+            num[j] = tv[j] * wv[j] + dist[r][j];
+            // x / x == 1 exactly for finite non-zero x (wn >= 1 whenever the weights are counts)
+            need |= upd[r][j] && !(num[j] == wn[j] && wn[j] < 3.0e38f && wn[j] > 0.0f);
+        }
+        float nt[4];
+        if (!ELIDE || __ballot(rowany[r] && need) != 0ull) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) nt[j] = num[j] / wn[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) nt[j] = 1.0f;
+        }
+        bool changed = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float newt = upd[r][j] ? nt[j] : tv[j];
+            changed |= __float_as_uint(newt) != __float_as_uint(tv[j]);
+            tv[j] = newt;
+            wv[j] = upd[r][j] ? wn[j] : wv[j];
+        }
+        const bool store_t = !ELIDE || __ballot(rowany[r] && changed) != 0ull;
+        if (rowany[r]) {
+            if (store_t) vol_store<NT>(p.tsdf + row0 + (size_t)r * p.dim_x, make_float4(tv[0], tv[1], tv[2], tv[3]));
+            vol_store<NT>(p.weight + row0 + (size_t)r * p.dim_x, make_float4(wv[0], wv[1], wv[2], wv[3]));
+        }
+    }
+}
+
+// Ceiling probe: the same 16 B/voxel read-modify-write stream with no geometry at all
+// (tsdf *= 1, weight += 0 keeps the grid intact).  What this reaches is what the memory
+// system gives this access pattern; Integrate is judged against it and against the 8 TB/s spec.
+template <bool NT>
+__global__ __launch_bounds__(256) void stream_rmw(float *tsdf, float *weight, size_t n_quads, float one,
+                                                  float zero)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_quads; q += stride) {
+        float4 t = vol_load<NT>(tsdf + 4 * q);
+        float4 w = vol_load<NT>(weight + 4 * q);
+        t.x *= one; t.y *= one; t.z *= one; t.w *= one;
+        w.x += zero; w.y += zero; w.z += zero; w.w += zero;
+        vol_store<NT>(tsdf + 4 * q, t);
+        vol_store<NT>(weight + 4 * q, w);
+    }
+}
+
 // TSDF = 1, weight = 0 (ref: src/tsdf.cu:79-81) written at bandwidth on the device.
 __global__ __launch_bounds__(256) void fill_grid(float *tsdf, float *weight, size_t n)
 {

@@ -1,0 +1,70 @@
+"""Drop-in proof: a C++ program written against include/tsdf.hpp exactly as the reference's
+Object.cpp uses its TSDF member (tests/dropin_callsite.cpp) produces, on the GPU, the files the
+reference's destructor would write -- compared byte for byte with the oracle's writers."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from semantic_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "semantic_slam_amd")
+
+
+def build_harness(tmp_path):
+    exe = str(tmp_path / "dropin_callsite")
+    subprocess.check_call(["g++", "-O1", "-std=c++11", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "dropin_callsite.cpp"), "-o", exe,
+                           "-L", PKG, "-ltsdf_dropin", "-ltsdf_hip", f"-Wl,-rpath,{PKG}"])
+    return exe
+
+
+def test_object_callsite_sequence(cuda, oracle, tmp_path):
+    assert os.path.isfile(os.path.join(PKG, "libtsdf_dropin.so")), "libtsdf_dropin.so not built"
+    exe = build_harness(tmp_path)
+    rng = np.random.default_rng(11)
+    vol_id = 7
+    dims, vs = (200, 200, 200), 0.004              # the reference's compile-time grid
+    trunc = float(np.float32(vs) * np.float32(5))
+    # a scene sized for that grid, seen by the first keyframe (= base frame, ref: src/Object.cpp:23-29)
+    grid_origin = np.array([-0.4, -0.4, 0.7], np.float32)
+    scene = synth.SurfScene(dims, vs, grid_origin)
+    base2world = synth.random_pose(rng, 0.2, 0.5)   # Twc of the first keyframe
+    frames = []
+    for k in range(3):
+        rel = scene.pose(2 * k, n=16)               # camera pose in the base frame
+        cam2world = oracle.multiply(base2world, rel)
+        # depth as the offline labeller prepares it (ref: examples/label_instance_rgbd.cpp:89-100),
+        # then masked per instance (ref: src/Engine.cpp:192-193)
+        raw = np.round(np.clip(scene.depth(rel), 0, 13.0) * 5000.0).astype(np.uint16)
+        depth = oracle.depth_prep(raw)
+        mask = np.zeros((480, 640), np.uint8)
+        mask[40:440, 60:600] = 255
+        frames.append((cam2world, oracle.mask_depth(depth, mask)))
+    # origin exactly as Object::Object derives it from the first masked depth (ref: src/Object.cpp:37-49)
+    origin = oracle.object_origin(frames[0][1], synth.TUM_K)
+
+    inp = tmp_path / "frames.bin"
+    with open(inp, "wb") as f:
+        f.write(struct.pack("<ii", vol_id, len(frames)))
+        f.write(base2world.astype(np.float32).tobytes())
+        f.write(origin.astype(np.float32).tobytes())
+        for c2w, d in frames:
+            f.write(c2w.astype(np.float32).tobytes())
+            f.write(d.astype(np.float32).tobytes())
+    subprocess.check_call([exe, str(inp)], cwd=str(tmp_path))
+
+    ref_t, ref_w = oracle.init_grid(dims)
+    for c2w, d in frames:
+        c2b = oracle.cam2base(base2world, c2w)
+        oracle.integrate(synth.TUM_K, c2b, d, dims, origin, vs, trunc, ref_t, ref_w)
+    assert ref_w.sum() > 1000, "scene must update voxels"
+    oracle.save_ply(str(tmp_path / "want.ply"), ref_t, ref_w, dims, vs, origin)
+    oracle.save_bin(str(tmp_path / "want.bin"), ref_t, dims, origin, vs, trunc)
+    assert (tmp_path / f"tsdf{vol_id}.bin").read_bytes() == (tmp_path / "want.bin").read_bytes()
+    assert (tmp_path / f"tsdf{vol_id}.ply").read_bytes() == (tmp_path / "want.ply").read_bytes()
