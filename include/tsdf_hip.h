@@ -125,7 +125,12 @@ int tsdf_copy_slices(tsdf_volume *vol, int32_t z_local, int32_t n_slices, void *
 /* Restore a slab from host arrays (resume from a saved state).  Synchronous. */
 int tsdf_upload(tsdf_volume *vol, const float *tsdf_host, const float *weight_host);
 
-/* Device addresses of the slab's two arrays (x-fastest, slab-local z). */
+/*
+ * Device addresses of the slab's two arrays (x-fastest, slab-local z).  The library keeps a
+ * small free-space summary of the TSDF array; after WRITING TSDF values through
+ * this pointer call tsdf_refresh_summary().  Reading needs nothing.
+ */
+int tsdf_refresh_summary(tsdf_volume *vol);
 int tsdf_device_ptrs(tsdf_volume *vol, float **tsdf_dev, float **weight_dev);
 
 /* Number of voxels in this handle's slab: dim_x * dim_y * (z_end - z_begin). */
@@ -182,6 +187,13 @@ int tsdf_integrate_sequence_timed(tsdf_volume *vol, const float *depth_dev, cons
  * (values unchanged), timed with HIP events.  non_temporal selects nt loads/stores.
  */
 int tsdf_probe_stream(tsdf_volume *vol, int32_t non_temporal, int32_t n_iters, float *elapsed_ms);
+
+/*
+ * Device self-test of the kernel's shared-reciprocal division against the compiler's IEEE
+ * division on n_samples pseudo-random operand pairs in the range the kernel uses it for
+ * (DESIGN.md section 4).  *mismatches must come back 0; first_bad = {n, d, got, want} otherwise.
+ */
+int tsdf_selftest_fastdiv(int32_t device, uint64_t seed, uint64_t n_samples, uint64_t *mismatches, float first_bad[4]);
 
 /* Select the Integrate kernel variant (0 = default; others are listed in DESIGN.md). */
 int tsdf_set_kernel_variant(tsdf_volume *vol, int32_t variant);

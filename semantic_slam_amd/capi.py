@@ -16,10 +16,10 @@ LIB_PATH = os.path.join(_PKG, "libtsdf_hip.so")
 ABI_SYMBOLS = [
     "tsdf_config_default", "tsdf_create", "tsdf_destroy", "tsdf_reset", "tsdf_integrate",
     "tsdf_integrate_device", "tsdf_integrate_cam2base", "tsdf_integrate_masked_device",
-    "tsdf_sync", "tsdf_download", "tsdf_copy_slices", "tsdf_upload", "tsdf_device_ptrs", "tsdf_slab_voxels",
+    "tsdf_sync", "tsdf_download", "tsdf_copy_slices", "tsdf_upload", "tsdf_refresh_summary", "tsdf_device_ptrs", "tsdf_slab_voxels",
     "tsdf_get_config", "tsdf_last_cam2base", "tsdf_set_stream", "tsdf_get_stream",
     "tsdf_count_surface", "tsdf_extract_surface", "tsdf_save_ply", "tsdf_save_bin",
-    "tsdf_integrate_sequence_timed", "tsdf_probe_stream", "tsdf_set_kernel_variant", "tsdf_last_error",
+    "tsdf_integrate_sequence_timed", "tsdf_probe_stream", "tsdf_selftest_fastdiv", "tsdf_set_kernel_variant", "tsdf_last_error",
     "tsdf_version", "tsdf_multiply_matrix", "tsdf_invert_matrix",
 ]
 
@@ -65,6 +65,7 @@ def load():
     L.tsdf_download.argtypes = [vp, vp, vp]
     L.tsdf_upload.argtypes = [vp, vp, vp]
     L.tsdf_copy_slices.argtypes = [vp, C.c_int32, C.c_int32, vp, vp]
+    L.tsdf_refresh_summary.argtypes = [vp]
     L.tsdf_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     L.tsdf_slab_voxels.argtypes = [vp]
     L.tsdf_slab_voxels.restype = C.c_int64
@@ -78,6 +79,7 @@ def load():
     L.tsdf_save_bin.argtypes = [vp, C.c_char_p]
     L.tsdf_integrate_sequence_timed.argtypes = [vp, vp, vp, C.c_int32, f32p]
     L.tsdf_probe_stream.argtypes = [vp, C.c_int32, C.c_int32, f32p]
+    L.tsdf_selftest_fastdiv.argtypes = [C.c_int32, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), f32p]
     L.tsdf_set_kernel_variant.argtypes = [vp, C.c_int32]
     L.tsdf_last_error.restype = C.c_char_p
     L.tsdf_version.restype = C.c_char_p
@@ -140,6 +142,14 @@ def invert_matrix(m):
     m = _f32(m, 16)
     ok = load().tsdf_invert_matrix(m.ctypes.data, out.ctypes.data)
     return bool(ok), out
+
+
+def selftest_fastdiv(n_samples, seed=1, device=0):
+    """Returns (mismatches, first_bad[4]) of the device division self-test."""
+    cnt = C.c_uint64()
+    bad = (C.c_float * 4)()
+    check(load().tsdf_selftest_fastdiv(device, seed, n_samples, C.byref(cnt), bad), "tsdf_selftest_fastdiv")
+    return cnt.value, list(bad)
 
 
 class Volume:

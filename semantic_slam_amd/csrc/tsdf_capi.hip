@@ -68,6 +68,11 @@ struct tsdf_volume {
     bool stage_used[kStageSlots];
     int stage_next;
     int variant;
+    // free-space summary (one word per 256-voxel row segment), see tsdf_kernels.hip.h
+    uint32_t *d_flags;
+    size_t n_flags;
+    int nseg;
+    bool flags_known_zero;
     // scratch for surface extraction (allocated on first use)
     void *d_scratch;
     size_t scratch_bytes;
@@ -101,6 +106,30 @@ tsdfk::IntegrateParams make_params(const tsdf_volume *v, const float *depth_dev,
     p.nz = c.z_end - c.z_begin; p.z_begin = c.z_begin;
     p.H = c.im_height; p.W = c.im_width;
     p.xgroups = (c.dim_x + vx - 1) / vx;
+    p.flags = v->d_flags;
+    p.nseg = v->nseg;
+    // The shared-reciprocal projection (tsdf_kernels.hip.h, fast_div2) is exact when no operand
+    // needs div_scale's pre-scaling: bound every camera-frame coordinate of the slab by
+    // sum_j |R_ij| * max|d_j| and keep it, and the intrinsics, far from the exponent limits.
+    // Anything else (including NaN/inf in the pose) takes the generic IEEE-division path.
+    {
+        const double ext[3] = {(double)(c.dim_x - 1) * c.voxel_size, (double)(c.dim_y - 1) * c.voxel_size,
+                               (double)(c.dim_z - 1) * c.voxel_size};
+        const double o[3] = {p.ox, p.oy, p.oz}, t[3] = {p.tx, p.ty, p.tz};
+        double dmax[3];
+        for (int k = 0; k < 3; ++k) dmax[k] = std::fmax(std::fabs(o[k] - t[k]), std::fabs(o[k] + ext[k] - t[k])) * 1.001 + 1e-30;
+        const double rows[3][3] = {{p.rx0, p.rx1, p.rx2}, {p.ry0, p.ry1, p.ry2}, {p.rz0, p.rz1, p.rz2}};
+        bool ok = true;
+        for (int i = 0; i < 3; ++i) {
+            double b = 0;
+            for (int k = 0; k < 3; ++k) b += std::fabs(rows[i][k]) * dmax[k];
+            ok = ok && (b < 5.7e17);  // 2^59; false for NaN/inf
+        }
+        ok = ok && std::fabs((double)p.fx) < 16384.0 && std::fabs((double)p.fy) < 16384.0 &&
+             std::fabs((double)p.cx) < 1048576.0 && std::fabs((double)p.cy) < 1048576.0 &&
+             c.im_width < (1 << 20) && c.im_height < (1 << 20);
+        p.fast_ok = ok ? 1 : 0;
+    }
     return p;
 }
 
@@ -109,14 +138,44 @@ tsdfk::IntegrateParams make_params(const tsdf_volume *v, const float *depth_dev,
 //   1        scalar kernel integrate_rows<1> (any dim_x)
 //   2        first version integrate_rows<4> (one row per wavefront, no elision)
 //   16 + c   experiments: c = (rsel << 2) | (elide << 1) | nt, R = 1, 2, 4 for rsel = 0, 1, 2
-constexpr int kDefaultTile = 16 + ((1 << 2) | (1 << 1) | 1);  // R = 2, elide, non-temporal (fastest measured)
+//   32 + c   the same with the free-space summary (needs elide = 1)
+//   48 + c   summary + early (speculative, frustum-gated) volume loads
+//   64 + c   early loads without the summary
+//   80 + c   summary + exact shared-reciprocal projection (fast_div2)
+//   96 + c   shared-reciprocal projection without the summary
+constexpr int kDefaultTile = 80 + ((1 << 2) | (1 << 1) | 1);  // R = 2, elide, nt, summary, fast projection
 
-template <int R, bool ELIDE, bool NT, bool MASKED>
+template <int R, bool ELIDE, bool NT, bool MASKED, bool SUM, bool EARLY = false, bool FAST = false>
 void launch_tile(const tsdf_volume *v, const tsdfk::IntegrateParams &p)
 {
     dim3 block(64, 4, 1);
     dim3 grid((p.xgroups + 63) / 64, (p.dim_y + 4 * R - 1) / (4 * R), p.nz);
-    hipLaunchKernelGGL((tsdfk::integrate_tile<R, ELIDE, NT, MASKED>), grid, block, 0, v->stream, p);
+    hipLaunchKernelGGL((tsdfk::integrate_tile<R, ELIDE, NT, MASKED, SUM, EARLY, FAST>), grid, block, 0, v->stream, p);
+}
+
+// Kernels that do not maintain the free-space summary must not leave stale "all ones" flags behind.
+int drop_summary(tsdf_volume *v)
+{
+    if (v->flags_known_zero || v->n_flags == 0) return TSDF_OK;
+    HIP_TRY(hipMemsetAsync(v->d_flags, 0, v->n_flags * sizeof(uint32_t), v->stream));
+    v->flags_known_zero = true;
+    return TSDF_OK;
+}
+
+int rebuild_summary(tsdf_volume *v)
+{
+    if (v->n_flags == 0 || v->n_vox == 0) return TSDF_OK;
+    const long long rows = (long long)v->cfg.dim_y * (v->cfg.z_end - v->cfg.z_begin);
+    dim3 block(64, 4, 1);
+    dim3 grid(v->nseg, (unsigned)((rows + 3) / 4), 1);
+    if (rows > 4ll * 65535) {  // 2-D grid limit: fall back to "nothing known"
+        v->flags_known_zero = false;
+        return drop_summary(v);
+    }
+    hipLaunchKernelGGL(tsdfk::recompute_flags, grid, block, 0, v->stream, v->d_tsdf, v->d_flags, v->cfg.dim_x, rows, v->nseg);
+    HIP_TRY(hipGetLastError());
+    v->flags_known_zero = false;
+    return TSDF_OK;
 }
 
 // Queue one Integrate launch.  Shapes are validated at tsdf_create, so the grid covers exactly
@@ -133,6 +192,16 @@ int launch_integrate(tsdf_volume *v, const float *depth_dev, const uint8_t *mask
     if (c.dim_x % 4 != 0) variant = 1;  // rows are not 16-byte aligned: scalar kernel
     const int vx = variant == 1 ? 1 : 4;
     tsdfk::IntegrateParams p = make_params(v, depth_dev, mask_dev, c2b, vx);
+    // which launches keep the free-space summary up to date: the SUM kernels (variants >= 32 and the
+    // masked form of the tile kernel); the rows kernels and the plain tile variants do not
+    const bool summary = variant != 1 && variant != 2 &&
+                         (mask_dev != nullptr || (variant >= 32 && variant < 64) || (variant >= 80 && variant < 96));
+    if (!summary) {
+        int rc = drop_summary(v);
+        if (rc) return rc;
+    } else {
+        v->flags_known_zero = false;
+    }
     if (variant == 1 || variant == 2) {
         dim3 block(64, 4, 1);
         dim3 grid((p.xgroups + 63) / 64, (c.dim_y + 3) / 4, nz);
@@ -144,10 +213,33 @@ int launch_integrate(tsdf_volume *v, const float *depth_dev, const uint8_t *mask
             else hipLaunchKernelGGL((tsdfk::integrate_rows<1, false>), grid, block, 0, v->stream, p);
         }
     } else if (mask_dev) {
-        launch_tile<2, true, true, true>(v, p);  // masked fusion uses the default configuration
+        launch_tile<2, true, true, true, true, false, true>(v, p);  // masked fusion uses the default configuration
+    } else if (variant >= 32) {
+        switch (variant - 32) {
+#define SUM_CASE(code, R, N, S, E) case code: launch_tile<R, true, N, false, S, E>(v, p); break;
+#define FAST_CASE(code, R, N, S) case code: launch_tile<R, true, N, false, S, false, true>(v, p); break;
+            FAST_CASE(48 + 2, 1, false, true) FAST_CASE(48 + 3, 1, true, true)
+            FAST_CASE(48 + 6, 2, false, true) FAST_CASE(48 + 7, 2, true, true)
+            FAST_CASE(48 + 10, 4, false, true) FAST_CASE(48 + 11, 4, true, true)
+            FAST_CASE(64 + 2, 1, false, false) FAST_CASE(64 + 3, 1, true, false)
+            FAST_CASE(64 + 6, 2, false, false) FAST_CASE(64 + 7, 2, true, false)
+            FAST_CASE(64 + 10, 4, false, false) FAST_CASE(64 + 11, 4, true, false)
+#undef FAST_CASE
+            SUM_CASE(2, 1, false, true, false) SUM_CASE(3, 1, true, true, false)
+            SUM_CASE(6, 2, false, true, false) SUM_CASE(7, 2, true, true, false)
+            SUM_CASE(10, 4, false, true, false) SUM_CASE(11, 4, true, true, false)
+            SUM_CASE(16 + 2, 1, false, true, true) SUM_CASE(16 + 3, 1, true, true, true)
+            SUM_CASE(16 + 6, 2, false, true, true) SUM_CASE(16 + 7, 2, true, true, true)
+            SUM_CASE(16 + 10, 4, false, true, true) SUM_CASE(16 + 11, 4, true, true, true)
+            SUM_CASE(32 + 2, 1, false, false, true) SUM_CASE(32 + 3, 1, true, false, true)
+            SUM_CASE(32 + 6, 2, false, false, true) SUM_CASE(32 + 7, 2, true, false, true)
+            SUM_CASE(32 + 10, 4, false, false, true) SUM_CASE(32 + 11, 4, true, false, true)
+#undef SUM_CASE
+            default: return fail(TSDF_ERR_INVALID, "unknown kernel variant %d", variant);
+        }
     } else {
         switch (variant - 16) {
-#define TILE_CASE(code, R, E, N) case code: launch_tile<R, E, N, false>(v, p); break;
+#define TILE_CASE(code, R, E, N) case code: launch_tile<R, E, N, false, false>(v, p); break;
             TILE_CASE(0, 1, false, false) TILE_CASE(1, 1, false, true)
             TILE_CASE(2, 1, true, false)  TILE_CASE(3, 1, true, true)
             TILE_CASE(4, 2, false, false) TILE_CASE(5, 2, false, true)
@@ -175,6 +267,10 @@ int fill(tsdf_volume *v)
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(tsdfk::fill_grid, dim3(blocks), dim3(256), 0, v->stream, v->d_tsdf, v->d_weight, n);
     HIP_TRY(hipGetLastError());
+    if (v->n_flags) {  // every TSDF value is 1: every segment flag is set
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)v->d_flags, 1, v->n_flags, v->stream));
+        v->flags_known_zero = false;
+    }
     return TSDF_OK;
 }
 
@@ -270,6 +366,10 @@ int tsdf_create(const tsdf_config *cfg, tsdf_volume **out)
     if ((e = hipMalloc((void **)&v->d_tsdf, bytes)) != hipSuccess ||
         (e = hipMalloc((void **)&v->d_weight, bytes)) != hipSuccess)
         return cleanup(fail(TSDF_ERR_HIP, "tsdf_create: hipMalloc of %zu bytes x2: %s", bytes, hipGetErrorString(e)));
+    v->nseg = (cfg->dim_x + 255) / 256;
+    v->n_flags = (size_t)v->nseg * cfg->dim_y * (size_t)(cfg->z_end - cfg->z_begin);
+    if ((e = hipMalloc((void **)&v->d_flags, (v->n_flags ? v->n_flags : 1) * sizeof(uint32_t))) != hipSuccess)
+        return cleanup(fail(TSDF_ERR_HIP, "tsdf_create: hipMalloc of the summary: %s", hipGetErrorString(e)));
     size_t img = (size_t)cfg->im_height * cfg->im_width * sizeof(float);
     for (int i = 0; i < kStageSlots; ++i) {
         if ((e = hipHostMalloc((void **)&v->h_stage[i], img, hipHostMallocDefault)) != hipSuccess ||
@@ -294,6 +394,7 @@ int tsdf_destroy(tsdf_volume *v)
         if (v->d_stage[i]) (void)hipFree(v->d_stage[i]);
     }
     if (v->d_scratch) (void)hipFree(v->d_scratch);
+    if (v->d_flags) (void)hipFree(v->d_flags);
     if (v->d_tsdf) (void)hipFree(v->d_tsdf);
     if (v->d_weight) (void)hipFree(v->d_weight);
     if (v->own_stream) (void)hipStreamDestroy(v->own_stream);
@@ -408,7 +509,16 @@ int tsdf_upload(tsdf_volume *v, const float *tsdf_host, const float *weight_host
     if (bytes == 0) return TSDF_OK;
     if (tsdf_host) HIP_TRY(hipMemcpy(v->d_tsdf, tsdf_host, bytes, hipMemcpyHostToDevice));
     if (weight_host) HIP_TRY(hipMemcpy(v->d_weight, weight_host, bytes, hipMemcpyHostToDevice));
+    if (tsdf_host) return rebuild_summary(v);
     return TSDF_OK;
+}
+
+int tsdf_refresh_summary(tsdf_volume *v)
+{
+    if (!v) return fail(TSDF_ERR_INVALID, "tsdf_refresh_summary: NULL handle");
+    int rc = bind_device(v);
+    if (rc) return rc;
+    return rebuild_summary(v);
 }
 
 int tsdf_device_ptrs(tsdf_volume *v, float **tsdf_dev, float **weight_dev)
@@ -455,9 +565,34 @@ int tsdf_get_stream(tsdf_volume *v, void **hip_stream)
 int tsdf_set_kernel_variant(tsdf_volume *v, int32_t variant)
 {
     if (!v) return fail(TSDF_ERR_INVALID, "tsdf_set_kernel_variant: NULL handle");
-    if (!(variant >= 0 && variant <= 2) && !(variant >= 16 && variant < 28))
+    const int c = (variant - 32) & 15;
+    const bool sum_ok = variant >= 32 && variant < 112 && c < 12 && ((c >> 1) & 1);
+    if (!(variant >= 0 && variant <= 2) && !(variant >= 16 && variant < 28) && !sum_ok)
         return fail(TSDF_ERR_INVALID, "tsdf_set_kernel_variant: unknown variant %d", variant);
     v->variant = variant;
+    return TSDF_OK;
+}
+
+int tsdf_selftest_fastdiv(int32_t device, uint64_t seed, uint64_t n_samples, uint64_t *mismatches, float first_bad[4])
+{
+    if (!mismatches || !first_bad) return fail(TSDF_ERR_INVALID, "tsdf_selftest_fastdiv: NULL argument");
+    HIP_TRY(hipSetDevice(device));
+    unsigned long long *d_cnt = nullptr;
+    float *d_bad = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_cnt, sizeof *d_cnt));
+    HIP_TRY(hipMalloc((void **)&d_bad, 4 * sizeof(float)));
+    HIP_TRY(hipMemset(d_cnt, 0, sizeof *d_cnt));
+    HIP_TRY(hipMemset(d_bad, 0, 4 * sizeof(float)));
+    hipLaunchKernelGGL(tsdfk::selftest_fastdiv, dim3(256 * 8), dim3(256), 0, 0, seed, n_samples, 535.4f, 320.1f, d_cnt, d_bad);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    unsigned long long cnt = 0;
+    if (e == hipSuccess) e = hipMemcpy(&cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(first_bad, d_bad, 4 * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d_cnt);
+    (void)hipFree(d_bad);
+    if (e != hipSuccess) return fail(TSDF_ERR_HIP, "tsdf_selftest_fastdiv: %s", hipGetErrorString(e));
+    *mismatches = cnt;
     return TSDF_OK;
 }
 

@@ -38,6 +38,12 @@ struct IntegrateParams {
     int nz, z_begin;        // slices in this slab, global z of the first
     int H, W;
     int xgroups;            // ceil(dim_x / VX)
+    // free-space summary: one word per 256-voxel row segment, non-zero = "every TSDF value of the
+    // segment is exactly 1.0f" (true after tsdf_create/tsdf_reset); index row * nseg + segment
+    uint32_t *flags;
+    int nseg;               // ceil(dim_x / 256)
+    // host-proved magnitude bounds that make the shared-reciprocal projection exact (see fast_div2)
+    int fast_ok;
 };
 
 // Terms of the camera-frame point that do not depend on x (shared by a lane's voxels).
@@ -145,16 +151,16 @@ __global__ __launch_bounds__(256) void integrate_rows(IntegrateParams p)
 }
 
 // ------------------------------------------------------------------------------------------
-// integrate_tile<R, ELIDE, NT, MASKED>: the tuned kernel.
+// integrate_tile<R, ELIDE, NT, MASKED, SUM, EARLY>: the tuned kernel.
 //
 // block = 64 x 4 threads; a lane owns a 4(x) x R(y) patch of one z slice, a wavefront
 // 256(x) x R(y).  grid = (ceil(xgroups/64), ceil(dim_y/(4R)), nz).  Needs dim_x % 4 == 0.
 //
 //  * the x-only products (rx0*dx, ry0*dx, rz0*dx) are computed once and shared by the R rows;
-//  * all 4R depth samples of a lane are gathered before any is used (branch-free geometry,
-//    rejected voxels read pixel 0), then all 2R volume quads are loaded together: two memory
-//    round trips per wavefront per R rows instead of two per row;
-//  * a wavefront with nothing to update leaves before touching the volume (__ballot);
+//  * geometry is branch-free (rejected voxels read pixel 0): all 4R depth samples of a lane are
+//    gathered back to back;
+//  * a wavefront with nothing to update never writes, and (without EARLY, or when the coarse
+//    frustum test rejects its patch) never reads the volume either (__ballot early-out);
 //  * ELIDE: arithmetic whose result is known exactly is skipped per wavefront --
 //      - diff >= trunc  =>  fmin(1, diff/trunc) == 1: no division unless some lane is inside
 //        the truncation band (correctly rounded a/b >= 1 whenever a >= b > 0);
@@ -164,7 +170,53 @@ __global__ __launch_bounds__(256) void integrate_rows(IntegrateParams p)
 //        (the weight always changes and is always stored).
 //    Every skipped value is the value the full computation would produce, bit for bit.
 //  * NT: volume loads/stores carry the non-temporal hint (each byte is touched once per frame).
+//  * SUM: free-space summary.  A wavefront's row is one 256-voxel segment with one flag word;
+//    while the flag says "all TSDF == 1" the TSDF quad is not loaded -- the constant 1 stands
+//    in for it and the same arithmetic runs on it -- so free space moves 8 B per voxel, not 12.
+//    The first update that leaves a value != 1 stores the row and clears the flag; flags are
+//    only ever set by fill_grid / recompute_flags (create, reset, upload).
+//  * EARLY: the kernel was limited by bytes in flight, not by bandwidth or VALU: a wavefront
+//    issued its volume loads only after ~1000 cycles of geometry plus a depth-gather round
+//    trip.  With EARLY the flag words and the weight quads (and, once the flags are back, the
+//    TSDF quads of rows that are not all-ones) are requested at the top of the kernel and
+//    arrive while the geometry runs.  The loads are speculative -- a patch may turn out to need
+//    nothing -- so they are gated by a coarse, wave-uniform test of the patch's four corners
+//    against the image; the gate only decides WHEN a quad is loaded, never what is computed
+//    (a lane that has to update a quad that was not pre-loaded loads it then), so it needs no
+//    rounding analysis.
 // ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------
+// Exact division, cheaper.  hipcc lowers an IEEE fp32 `n / d` to
+//     s_d = div_scale(d), s_n = div_scale(n)          (power-of-two pre-scaling, extreme exponents only)
+//     r0 = rcp(s_d); e0 = fma(-s_d, r0, 1); r1 = fma(e0, r0, r0)
+//     q0 = s_n*r1;   e1 = fma(-s_d, q0, s_n); q1 = fma(e1, r1, q0)
+//     e2 = fma(-s_d, q1, s_n); q = div_fmas(e2, r1, q1); div_fixup(q, d, n)     (11 instructions)
+// For operands whose exponents are far from the ends of the range div_scale returns its input,
+// div_fmas is a plain fma and div_fixup passes q through, so the seven instructions in the
+// middle ARE the correctly rounded quotient.  fast_div2 runs exactly those on a pair of
+// numerators that share one denominator -- the reciprocal refinement is done once, the rest is
+// two-wide packed math (v_pk_mul_f32 / v_pk_fma_f32, full rate on gfx950): 3 + 5 instructions
+// for both quotients instead of 22.  Bit-identity with `/` over the guarded range is checked
+// on the device by tsdf_selftest_fastdiv (tests/test_gpu_fastdiv.py); the guard is in the kernel.
+// ------------------------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2f fast_div2(v2f n, float d)
+{
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float e0 = __builtin_fmaf(-d, r0, 1.0f);
+    const float r1 = __builtin_fmaf(e0, r0, r0);
+    const v2f R = {r1, r1}, D = {d, d};
+    const v2f q0 = n * R;
+    const v2f e1 = __builtin_elementwise_fma(-D, q0, n);
+    const v2f q1 = __builtin_elementwise_fma(e1, R, q0);
+    const v2f e2 = __builtin_elementwise_fma(-D, q1, n);
+    return __builtin_elementwise_fma(e2, R, q1);
+}
+
+// Denominators the fast path accepts; numerators are bounded by the host (IntegrateParams::fast_ok).
+#define TSDF_FAST_D_MIN 8.6736174e-19f   /* 2^-60 */
+
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 template <bool NT>
@@ -188,7 +240,36 @@ __device__ __forceinline__ void vol_store(float *p, float4 v)
     }
 }
 
-template <int R, bool ELIDE, bool NT, bool MASKED>
+// Coarse frustum gate for the speculative loads: true unless the patch's four corners
+// (x0|x1, y0|y1 at slice gz) are all behind the camera or all beyond the same image edge by
+// more than one pixel.  Lanes 0..3 each project one corner; approximate arithmetic is fine.
+__device__ __forceinline__ bool patch_may_be_visible(const IntegrateParams &p, int x0, int x1, int y0,
+                                                     int y1, int gz)
+{
+    const int lane = threadIdx.x & 63;
+    const float bx = p.ox + (float)((lane & 1) ? x1 : x0) * p.vs - p.tx;
+    const float by = p.oy + (float)((lane & 2) ? y1 : y0) * p.vs - p.ty;
+    const float bz = p.oz + (float)gz * p.vs - p.tz;
+    const float cx = p.rx0 * bx + p.rx1 * by + p.rx2 * bz;
+    const float cy = p.ry0 * bx + p.ry1 * by + p.ry2 * bz;
+    const float cz = p.rz0 * bx + p.rz1 * by + p.rz2 * bz;
+    const float inv = __builtin_amdgcn_rcpf(cz);
+    const float u = p.fx * (cx * inv) + p.cx;
+    const float v = p.fy * (cy * inv) + p.cy;
+    const bool corner = lane < 4;
+    const bool front = cz > 0.0f;
+    const unsigned long long m = __ballot(corner);
+    const bool all_front = (__ballot(corner && front) == m);
+    if (__ballot(corner && !front) == m) return false;          // wholly behind the camera
+    if (!all_front) return true;                                 // straddles the camera plane: no claim
+    if (__ballot(corner && u < -1.0f) == m) return false;
+    if (__ballot(corner && u > (float)p.W) == m) return false;
+    if (__ballot(corner && v < -1.0f) == m) return false;
+    if (__ballot(corner && v > (float)p.H) == m) return false;
+    return true;
+}
+
+template <int R, bool ELIDE, bool NT, bool MASKED, bool SUM = false, bool EARLY = false, bool FAST = false>
 __global__ __launch_bounds__(256) void integrate_tile(IntegrateParams p)
 {
     const int xg = blockIdx.x * 64 + threadIdx.x;
@@ -196,6 +277,42 @@ __global__ __launch_bounds__(256) void integrate_tile(IntegrateParams p)
     const int lz = blockIdx.z;
     if (xg >= p.xgroups || gy0 >= p.dim_y) return;
     const int gz = p.z_begin + lz;
+    const size_t row0 = ((size_t)lz * p.dim_y + gy0) * (size_t)p.dim_x + (size_t)xg * 4;
+    const size_t flag0 = ((size_t)lz * p.dim_y + gy0) * (size_t)p.nseg + blockIdx.x;
+
+    // ---- phase 0: summary flags, and (EARLY) the speculative volume loads -----------------------
+    uint32_t fl[R];
+    float4 t4[R], w4[R];
+    bool have_w[R], have_t[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        fl[r] = 0u;
+        if (SUM && gy0 + r < p.dim_y) fl[r] = p.flags[flag0 + (size_t)r * p.nseg];
+        t4[r] = make_float4(1.f, 1.f, 1.f, 1.f);
+        w4[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        have_w[r] = have_t[r] = false;
+    }
+    if (EARLY) {
+        const int x_first = blockIdx.x * 256;
+        const int x_last = min(x_first + 255, p.dim_x - 1);
+        const int y_last = min(gy0 + R - 1, p.dim_y - 1);
+        if (patch_may_be_visible(p, x_first, x_last, gy0, y_last, gz)) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (gy0 + r < p.dim_y) {
+                    w4[r] = vol_load<NT>(p.weight + row0 + (size_t)r * p.dim_x);
+                    have_w[r] = true;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (gy0 + r < p.dim_y && !(SUM && fl[r] != 0u)) {
+                    t4[r] = vol_load<NT>(p.tsdf + row0 + (size_t)r * p.dim_x);
+                    have_t[r] = true;
+                }
+            }
+        }
+    }
 
     // x-only and z-only terms (ref: src/tsdf.cu:27,29,33,35-38)
     float ax[4], ay[4], az[4];
@@ -212,29 +329,80 @@ __global__ __launch_bounds__(256) void integrate_tile(IntegrateParams p)
     // ---- phase 1: geometry of all 4R voxels, depth gathers issued back to back --------------
     float pcz[R][4], dval[R][4];
     bool geo[R][4];
+    int pixel[R][4];
+    // camera-frame z of every voxel first: it decides which projection path the wavefront takes
+    bool unsafe = false;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int gy = gy0 + r;
-        const bool row_ok = gy < p.dim_y;
-        const float by = p.oy + (float)gy * p.vs;   // ref: src/tsdf.cu:28
-        const float dy = by - p.ty;
-        const float x1 = p.rx1 * dy, y1 = p.ry1 * dy, z1 = p.rz1 * dy;
+        const float dy = (p.oy + (float)(gy0 + r) * p.vs) - p.ty;   // ref: src/tsdf.cu:28,34
+        const float z1 = p.rz1 * dy;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float cx = ax[j] + x1 + x2;
-            const float cy = ay[j] + y1 + y2;
             const float cz = az[j] + z1 + z2;
             pcz[r][j] = cz;
-            // ref: src/tsdf.cu:39-43.  cz <= 0 is tested before the quotient is used, exactly
-            // as the reference's `continue`; the division itself is harmless for any cz.
-            const float pu = roundf(p.fx * (cx / cz) + p.cx);
-            const float pv = roundf(p.fy * (cy / cz) + p.cy);
-            const bool ok = row_ok && !(cz <= 0.0f) && pu >= 0.0f && pu < (float)p.W && pv >= 0.0f &&
-                            pv < (float)p.H;
-            geo[r][j] = ok;
-            const int pix = ok ? (int)pv * p.W + (int)pu : 0;
-            float d = p.depth[pix];
-            if (MASKED) d = d * (p.mask[pix] >= 128 ? 1.0f : 0.0f);  // ref: src/Engine.cpp:192-193
+            unsafe |= cz > 0.0f && cz < TSDF_FAST_D_MIN;
+        }
+    }
+    const bool fast = FAST && p.fast_ok != 0 && __ballot(unsafe) == 0ull;   // wave-uniform
+    if (fast) {
+        // Same values as the generic branch below, obtained with fewer instructions:
+        //  - both quotients of a voxel from one refined reciprocal (fast_div2), packed;
+        //  - (cx, cy) sums, fx*q + cx / fy*q + cy as two-wide packed operations;
+        //  - roundf(u) for u > -0.5 is trunc(u) + (u - trunc(u) >= 0.5); u <= -0.5 (and NaN) can
+        //    only round to a negative pixel, which ref: src/tsdf.cu:43 rejects -- so the lower
+        //    bound is tested on u itself and the sign handling of roundf is not needed.
+        const v2f F = {p.fx, p.fy}, C = {p.cx, p.cy};
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool row_ok = gy0 + r < p.dim_y;
+            const float dy = (p.oy + (float)(gy0 + r) * p.vs) - p.ty;
+            const v2f XY1 = {p.rx1 * dy, p.ry1 * dy};
+            const v2f XY2 = {x2, y2};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const v2f A = {ax[j], ay[j]};
+                const v2f n = A + XY1 + XY2;                       // (pt_cam_x, pt_cam_y), ref: :36-37
+                const float cz = pcz[r][j];
+                const v2f uv = F * fast_div2(n, cz) + C;           // ref: :41-42 before rounding
+                const v2f tr = {__builtin_truncf(uv.x), __builtin_truncf(uv.y)};
+                const v2f fr = uv - tr;                            // exact
+                const v2f rd = {tr.x + (fr.x >= 0.5f ? 1.0f : 0.0f), tr.y + (fr.y >= 0.5f ? 1.0f : 0.0f)};
+                const bool ok = row_ok && cz > 0.0f && uv.x > -0.5f && uv.y > -0.5f && rd.x < (float)p.W &&
+                                rd.y < (float)p.H;
+                geo[r][j] = ok;
+                pixel[r][j] = ok ? (int)rd.y * p.W + (int)rd.x : 0;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int gy = gy0 + r;
+            const bool row_ok = gy < p.dim_y;
+            const float by = p.oy + (float)gy * p.vs;   // ref: src/tsdf.cu:28
+            const float dy = by - p.ty;
+            const float x1 = p.rx1 * dy, y1 = p.ry1 * dy;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float cx = ax[j] + x1 + x2;
+                const float cy = ay[j] + y1 + y2;
+                const float cz = pcz[r][j];
+                // ref: src/tsdf.cu:39-43.  cz <= 0 is tested before the quotient is used, exactly
+                // as the reference's `continue`; the division itself is harmless for any cz.
+                const float pu = roundf(p.fx * (cx / cz) + p.cx);
+                const float pv = roundf(p.fy * (cy / cz) + p.cy);
+                const bool ok = row_ok && !(cz <= 0.0f) && pu >= 0.0f && pu < (float)p.W && pv >= 0.0f &&
+                                pv < (float)p.H;
+                geo[r][j] = ok;
+                pixel[r][j] = ok ? (int)pv * p.W + (int)pu : 0;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float d = p.depth[pixel[r][j]];
+            if (MASKED) d = d * (p.mask[pixel[r][j]] >= 128 ? 1.0f : 0.0f);  // ref: src/Engine.cpp:192-193
             dval[r][j] = d;
         }
     }
@@ -258,19 +426,15 @@ __global__ __launch_bounds__(256) void integrate_tile(IntegrateParams p)
         }
         any |= rowany[r];
     }
-    if (__ballot(any) == 0ull) return;  // wavefront early-out: no volume traffic at all
+    if (__ballot(any) == 0ull) return;  // wavefront early-out: nothing is written
     if (!any) return;
 
-    // ---- phase 3: volume quads in, truncated distance ----------------------------------------
-    const size_t row0 = ((size_t)lz * p.dim_y + gy0) * (size_t)p.dim_x + (size_t)xg * 4;
-    float4 t4[R], w4[R];
+    // ---- phase 3: whatever was not pre-loaded; truncated distance -------------------------------
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        t4[r] = make_float4(1.f, 1.f, 1.f, 1.f);
-        w4[r] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (rowany[r]) {
-            t4[r] = vol_load<NT>(p.tsdf + row0 + (size_t)r * p.dim_x);
-            w4[r] = vol_load<NT>(p.weight + row0 + (size_t)r * p.dim_x);
+            if (!have_w[r]) w4[r] = vol_load<NT>(p.weight + row0 + (size_t)r * p.dim_x);
+            if (!have_t[r] && !(SUM && fl[r] != 0u)) t4[r] = vol_load<NT>(p.tsdf + row0 + (size_t)r * p.dim_x);
         }
     }
     float dist[R][4];
@@ -308,18 +472,69 @@ __global__ __launch_bounds__(256) void integrate_tile(IntegrateParams p)
 #pragma unroll
             for (int j = 0; j < 4; ++j) nt[j] = 1.0f;
         }
-        bool changed = false;
+        bool changed = false, notone = false;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float newt = upd[r][j] ? nt[j] : tv[j];
             changed |= __float_as_uint(newt) != __float_as_uint(tv[j]);
+            notone |= upd[r][j] && __float_as_uint(newt) != 0x3f800000u;
             tv[j] = newt;
             wv[j] = upd[r][j] ? wn[j] : wv[j];
+        }
+        if (SUM && fl[r] != 0u && __ballot(notone) != 0ull) {
+            if (notone) p.flags[flag0 + (size_t)r * p.nseg] = 0u;  // segment no longer all ones
         }
         const bool store_t = !ELIDE || __ballot(rowany[r] && changed) != 0ull;
         if (rowany[r]) {
             if (store_t) vol_store<NT>(p.tsdf + row0 + (size_t)r * p.dim_x, make_float4(tv[0], tv[1], tv[2], tv[3]));
             vol_store<NT>(p.weight + row0 + (size_t)r * p.dim_x, make_float4(wv[0], wv[1], wv[2], wv[3]));
+        }
+    }
+}
+
+// Device self-test of fast_div2 against the compiler's IEEE division: pseudo-random operands from a
+// counter hash, denominators in [2^-60, 2^60], numerators up to 2^60 in magnitude (plus exact
+// zeros and structured mantissas).  A sample passes when the quotients are bit-identical, or --
+// for quotients below 2^-42, where the unscaled sequence may lose the last bit of a denormal
+// residual -- when the pixel coordinate fl(f*q + c) the kernel derives from it is identical.
+__device__ __forceinline__ uint32_t hash32(uint64_t x)
+{
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+    return (uint32_t)x;
+}
+
+__global__ __launch_bounds__(256) void selftest_fastdiv(uint64_t seed, uint64_t n_samples, float fx, float cx,
+                                                        unsigned long long *mismatch, float *first_bad)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_samples; i += stride) {
+        const uint32_t h0 = hash32(seed + 3 * i), h1 = hash32(seed + 3 * i + 1), h2 = hash32(seed + 3 * i + 2);
+        const uint32_t mode = h2 & 7u;
+        // denominator: exponent in [-60, 60], mantissa random / all ones / all zeros
+        uint32_t dm = h0 & 0x7fffffu;
+        if (mode == 1) dm = 0x7fffffu; else if (mode == 2) dm = 0u; else if (mode == 3) dm &= 0x7u;
+        const uint32_t de = 127u - 60u + (h0 >> 23) % 121u;
+        const float d = __uint_as_float((de << 23) | dm);
+        // numerators: sign, exponent in [-149, 60] for one, near the denominator for the other
+        uint32_t ne = (mode >= 6) ? ((h1 >> 23) % 190u) : (de - 12u + (h1 >> 23) % 24u);
+        if (ne > 127u + 60u) ne = 127u + 60u;
+        uint32_t nm = h1 & 0x7fffffu;
+        if (mode == 4) nm = 0x7fffffu; else if (mode == 5) nm = dm;
+        float n0 = __uint_as_float(((h2 >> 3) & 1u) << 31 | (ne << 23) | nm);
+        float n1 = __uint_as_float(((h2 >> 4) & 1u) << 31 | (((ne + (h2 >> 8) % 5u) % 188u) << 23) | (h2 >> 9));
+        if ((h2 >> 5 & 31u) == 0u) n0 = 0.0f;
+        const v2f nn = {n0, n1};
+        const v2f q = fast_div2(nn, d);
+        const float r0 = n0 / d, r1 = n1 / d;
+        bool bad0 = __float_as_uint(q.x) != __float_as_uint(r0);
+        bool bad1 = __float_as_uint(q.y) != __float_as_uint(r1);
+        if (bad0 && fabsf(r0) < 2.2737368e-13f) bad0 = __float_as_uint(fx * q.x + cx) != __float_as_uint(fx * r0 + cx);
+        if (bad1 && fabsf(r1) < 2.2737368e-13f) bad1 = __float_as_uint(fx * q.y + cx) != __float_as_uint(fx * r1 + cx);
+        if (bad0 || bad1) {
+            if (atomicAdd(mismatch, 1ull) == 0ull) {
+                first_bad[0] = bad0 ? n0 : n1; first_bad[1] = d; first_bad[2] = bad0 ? q.x : q.y;
+                first_bad[3] = bad0 ? r0 : r1;
+            }
         }
     }
 }
@@ -340,6 +555,21 @@ __global__ __launch_bounds__(256) void stream_rmw(float *tsdf, float *weight, si
         vol_store<NT>(tsdf + 4 * q, t);
         vol_store<NT>(weight + 4 * q, w);
     }
+}
+
+// Rebuild the free-space summary from the TSDF array (after tsdf_upload or an external write):
+// one wavefront per 256-voxel row segment.  block = 64 x 4, grid = (nseg, ceil(rows/4)).
+__global__ __launch_bounds__(256) void recompute_flags(const float *tsdf, uint32_t *flags, int dim_x,
+                                                       long long n_rows, int nseg)
+{
+    const long long row = (long long)blockIdx.y * 4 + threadIdx.y;
+    if (row >= n_rows) return;
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    bool ones = true;
+    for (int j = 0; j < 4; ++j)
+        if (x0 + j < dim_x) ones &= __float_as_uint(tsdf[(size_t)row * dim_x + x0 + j]) == 0x3f800000u;
+    const bool all = __ballot(!ones) == 0ull;
+    if (threadIdx.x == 0) flags[(size_t)row * nseg + blockIdx.x] = all ? 1u : 0u;
 }
 
 // TSDF = 1, weight = 0 (ref: src/tsdf.cu:79-81) written at bandwidth on the device.

@@ -70,7 +70,12 @@ def test_integrate_matches_oracle(cuda, oracle, dims, vs, z0, rand_base, frames)
     assert_parity(got_t, got_w, ref_t, ref_w)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2] + list(range(16, 28)))
+# free-space summary (32+), summary + early loads (48+), early loads only (64+)
+# ... and the exact shared-reciprocal projection with (80+) / without (96+) the summary
+SUM_VARIANTS = [b + c for b in (32, 48, 64, 80, 96) for c in (2, 3, 6, 7, 10, 11)]
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2] + list(range(16, 28)) + SUM_VARIANTS)
 def test_every_kernel_variant_is_bit_exact(cuda, oracle, variant):
     """All kernel variants (rows/tile, R = 1/2/4, elision on/off, nt on/off) give identical bits.
     The scene has free space (elided divisions), a truncation band and repeated frames, so both
@@ -92,6 +97,48 @@ def test_every_kernel_variant_is_bit_exact(cuda, oracle, variant):
         got_t, got_w = vol.download()
     assert np.count_nonzero(ref_t != 1.0) > 1000 and ref_w.max() >= 3
     assert_parity(got_t, got_w, ref_t, ref_w)
+
+
+def test_free_space_summary_stays_consistent(cuda, oracle):
+    """The free-space summary (flags: "this 256-voxel segment is all ones") across every event that
+    can invalidate it: truncation-band updates, switching to kernels that do not maintain it and
+    back, upload of a foreign state, reset."""
+    dims, vs = (512, 24, 20), 0.005          # two segments per row
+    origin = synth.surf_volume(512, vs, 0.6)
+    cfg = capi.make_config(dims, vs, origin)
+    scene = synth.SurfScene(dims, vs, origin)
+    ref_t, ref_w = oracle.init_grid(dims)
+    far = np.full((480, 640), 5.9, np.float32)   # free space everywhere: the fast path
+    with capi.Volume(cfg) as vol:
+        def step(depth, pose, variant):
+            vol.set_kernel_variant(variant)
+            d_dev = dev(cuda, depth)
+            vol.integrate_device(d_dev.data_ptr(), pose)
+            vol.sync()
+            oracle.integrate(cfg.cam_K, pose, depth, dims, origin, vs, cfg.trunc_margin, ref_t, ref_w)
+
+        p0, p1 = scene.pose(0, 8), scene.pose(2, 8)
+        step(far, p0, 0)                      # all segments stay "ones"
+        step(scene.depth(p0), p0, 0)          # surface: some segments leave the ones state
+        step(far, p1, 0)                      # free space again over changed segments: must use real TSDF
+        step(scene.depth(p1), p1, 2)          # a kernel without summary support
+        step(far, p0, 0)                      # back on the summary kernel
+        t, w = vol.download()
+        assert_parity(t, w, ref_t, ref_w)
+        # foreign state: zeros in "free" segments
+        t2 = ref_t.copy(); t2[::3] = 0.25
+        vol.upload(t2, ref_w)
+        ref_t[:] = t2
+        step(far, p1, 0)
+        t, w = vol.download()
+        assert_parity(t, w, ref_t, ref_w)
+        vol.reset()
+        ref_t[:], ref_w[:] = 1.0, 0.0
+        step(far, p0, 0)
+        step(scene.depth(p0), p0, 39)
+        t, w = vol.download()
+        assert_parity(t, w, ref_t, ref_w)
+    assert np.count_nonzero(ref_t != 1.0) > 1000
 
 
 def test_host_depth_path_equals_device_path(cuda, oracle):

@@ -11,7 +11,7 @@ from semantic_slam_amd import capi, synth  # noqa: E402
 
 D = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 workload = sys.argv[2] if len(sys.argv) > 2 else "sfull"
-variants = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else [2] + list(range(16, 28))
+variants = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else [2, 17, 23, 39, 43] + [b + c for b in (80, 96) for c in (3, 7, 11)]
 vs = {512: 0.005, 1024: 0.002}.get(D, 2.56 / D)
 dims = (D, D, D)
 if workload == "sfull":
@@ -35,14 +35,15 @@ res = {}
 for rnd in range(3):
     for v in variants:
         vol.set_kernel_variant(v)
+        vol.reset()   # same starting state for every variant (and a valid free-space summary)
         vol.integrate_sequence_timed(d.data_ptr(), poses[:5])
         ms = vol.integrate_sequence_timed(d.data_ptr(), poses) / len(poses)
         res.setdefault(v, []).append(ms)
 _, w = vol.download()
-upd = float(w.astype(np.float64).sum()) / (3 * len(variants) * (len(poses) + 5))
+upd = float(w.astype(np.float64).sum()) / (len(poses) + 5)
 print(f"workload {workload} D={D}: updated fraction {upd / N:.3f}")
 for v in variants:
     ms = min(res[v]); med = sorted(res[v])[1]
-    c = v - 16
-    desc = "rows<4> v0" if v == 2 else f"tile R={[1, 2, 4][c >> 2]} elide={(c >> 1) & 1} nt={c & 1}"
+    c = (v - 16) & 15
+    desc = "rows<4> v0" if v == 2 else f"tile R={[1, 2, 4][c >> 2]} elide={(c >> 1) & 1} nt={c & 1} sum={int(32 <= v < 64 or 80 <= v < 96)} early={int(48 <= v < 80)} fast={int(v >= 80)}"
     print(f"variant {v:2d} {desc:28s} min {ms:.4f} med {med:.4f} ms  {N / ms / 1e3:9.0f} Mvox/s  alg {(16 * upd + 1.2e6) / ms / 1e6:7.0f} GB/s")
