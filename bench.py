@@ -165,19 +165,25 @@ def main():
     del t_host, w_host
 
     # --- roofline of the dominant kernel (integrate_tile) on this rank -------------------------
-    # Bytes the frame must move (DESIGN.md "Bytes model"): per updated voxel 4 B TSDF read + 4 B
-    # weight read + 4 B weight write, plus 4 B TSDF write only where the value changes (the kernel
-    # does not store unchanged TSDF rows), plus one pass over the depth frame and the parameters.
-    # SURVEY.md section 8(d) counted 16 B for every updated voxel; that figure is reported beside it.
+    # Bytes the frame must move (DESIGN.md "Bytes model"): per updated voxel 4 B weight read + 4 B
+    # weight write; the TSDF value is read only where the free-space summary does not already say
+    # "this 256-voxel segment is all ones" and written only where it changes; plus the summary
+    # words themselves, one pass over the depth frame and the parameters.  SURVEY.md section 8(d)
+    # counted 16 B for every updated voxel; that figure is reported beside it.
     H, W = depth.shape
-    if args.workload == "sfull" or args.variant in (2, 16, 17, 20, 21, 24, 25):
-        n_tsdf_written = 0.0 if (args.workload == "sfull" and args.variant not in (2, 16, 17, 20, 21, 24, 25)) \
-            else n_upd_per_launch
-        tsdf_write_note = "exact"
+    v = args.variant
+    has_summary = v == 0 or 32 <= v < 64 or 80 <= v < 96
+    has_elide = has_summary or v in (18, 19, 22, 23, 26, 27) or v >= 64
+    if args.workload == "sfull":
+        # every voxel updated, every TSDF value stays exactly 1 (asserted above)
+        n_t_read = 0.0 if has_summary else n_upd_per_launch
+        n_t_written = 0.0 if has_elide else n_upd_per_launch
+        count_note = "exact"
     else:
-        n_tsdf_written = n_upd_per_launch   # upper bound: changed voxels are not counted on the device
-        tsdf_write_note = "upper bound (every updated voxel counted as changed)"
-    bytes_per_launch = 12.0 * n_upd_per_launch + 4.0 * n_tsdf_written + 4.0 * H * W + 100.0
+        n_t_read = n_t_written = n_upd_per_launch
+        count_note = "upper bound (TSDF reads/writes elided on the device are not counted there)"
+    flag_bytes = 4.0 * n_slab / 256.0 if has_summary else 0.0
+    bytes_per_launch = 8.0 * n_upd_per_launch + 4.0 * n_t_read + 4.0 * n_t_written + flag_bytes + 4.0 * H * W + 100.0
     bytes_survey = 16.0 * n_upd_per_launch + 4.0 * H * W + 100.0
     kernel_ms = kernel_ms_total / args.steps
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
@@ -217,17 +223,53 @@ def main():
                    "kernel_variant": args.variant},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "kernel": "tsdfk::integrate_tile<2,true,true,false>" if args.variant == 0 else f"variant {args.variant}",
+                     "kernel": "tsdfk::integrate_tile<R=2,ELIDE,NT,SUM,FAST>" if args.variant == 0 else f"variant {args.variant}",
                      "kernel_ms": round(kernel_ms, 5),
                      "algorithmic_bytes_per_launch": int(bytes_per_launch),
                      "voxels_updated_per_launch": int(n_upd_per_launch),
-                     "tsdf_values_written_per_launch": int(n_tsdf_written),
-                     "tsdf_write_count": tsdf_write_note,
-                     "bytes_model": "12 B per updated voxel + 4 B per changed TSDF value + 4*H*W + 100",
+                     "tsdf_values_read_per_launch": int(n_t_read),
+                     "tsdf_values_written_per_launch": int(n_t_written),
+                     "tsdf_counts": count_note,
+                     "bytes_model": "8 B per updated voxel (weight r+w) + 4 B per TSDF value read + 4 B per TSDF value "
+                                    "written + 4 B per 256-voxel summary word + 4*H*W + 100",
                      "survey_16B_model": {"bytes_per_launch": int(bytes_survey), "achieved": round(achieved_survey, 1),
                                           "frac": round(achieved_survey / HBM_PEAK_GBS, 4)},
                      "note": "per-rank slab launch; average over the timed steps from HIP events on the launch stream"},
     }
+    if world == 1 and args.variant == 0:
+        # The same workload through the plain streaming variant (no elision, no summary: all 16 B per
+        # updated voxel really move).  This is the kernel to read as "how close to the HBM roofline
+        # does the access pattern get"; the default kernel above is faster because it moves fewer bytes.
+        vol.set_kernel_variant(17)
+        vol.reset()
+        vol.integrate_sequence_timed(d_dev.data_ptr(), pose_block(0, 10))
+        n_s = min(args.steps, 200)
+        ms_s = vol.integrate_sequence_timed(d_dev.data_ptr(), pose_block(10, n_s)) / n_s
+        _, w_s = vol.download()
+        upd_s = float(w_s.astype(np.float64).sum()) / (10 + n_s)
+        del w_s
+        b_s = 16.0 * upd_s + 4.0 * H * W + 100.0
+        line["roofline"]["streaming_variant"] = {
+            "kernel": "tsdfk::integrate_tile<R=1,NT> (variant 17): 16 B per updated voxel, nothing elided",
+            "kernel_ms": round(ms_s, 5), "bytes_per_launch": int(b_s),
+            "achieved": round(b_s / (ms_s * 1e-3) / 1e9, 1), "frac": round(b_s / (ms_s * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "value": round(D ** 3 / ms_s / 1e3, 1), "unit": "GB/s (value: Mvoxels/s)"}
+        vol.set_kernel_variant(0)
+        vol.reset()
+    if world == 1:
+        # PCIe-inclusive rate of the reference-style call (tsdf_integrate: host depth pointer, staged
+        # through the pinned ring, 1.2 MB H2D per frame).  Reported beside the headline, never as it.
+        n_host = min(args.steps, 200)
+        vol.sync()
+        t1 = time.perf_counter()
+        for k in range(n_host):
+            vol.integrate(depth, poses[k % n_pose])
+        vol.sync()
+        dt = time.perf_counter() - t1
+        line["host_depth_path"] = {"ms_per_step": round(dt / n_host * 1e3, 5),
+                                   "value": round(D ** 3 * n_host / dt / 1e6, 1), "unit": "Mvoxels/s",
+                                   "note": "tsdf_integrate with a host depth pointer: memcpy to pinned staging + "
+                                           "H2D copy + kernel per frame, Python ctypes call overhead included"}
     if not args.no_cpu_baseline and world == 1:
         per_slice = D * D if args.workload == "sfull" else None
         base, ref = cpu_baseline(args, dims, vs, origin, cfg, depth, poses, per_slice)

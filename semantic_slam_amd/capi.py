@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libtsdf_hip.so")
+# TSDF_HIP_LIB overrides the library path (A/B timing of two builds on one GPU box; tools/sweep.py)
+LIB_PATH = os.environ.get("TSDF_HIP_LIB") or os.path.join(_PKG, "libtsdf_hip.so")
 
 # every symbol include/tsdf_hip.h declares (tests check the .so exports exactly these)
 ABI_SYMBOLS = [
