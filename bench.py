@@ -32,6 +32,8 @@ def parse():
     ap.add_argument("--grid", type=int, default=512, help="grid edge in voxels (512 or 1024)")
     ap.add_argument("--workload", default="sfull", choices=["sfull", "ssurf"])
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (see DESIGN.md)")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="single-GPU rehearsal of one rank of an N-GPU job: integrate only rank 0's z-slab of N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
     return ap.parse_args()
@@ -125,6 +127,8 @@ def main():
 
     # z-slab of this rank (ref layout is z-major, so a slab is one contiguous range)
     zb, ze = rank * D // world, (rank + 1) * D // world
+    if args.emulate_world > 1 and world == 1:
+        zb, ze = 0, D // args.emulate_world
     cfg = capi.make_config(dims, vs, origin, z_begin=zb, z_end=ze, device=local_rank)
     vol = capi.Volume(cfg)
     vol.set_kernel_variant(args.variant)
@@ -207,7 +211,7 @@ def main():
 
     line = {
         "metric": f"Mvoxels/sec integrated, {D}^3 grid @ 640x480 depth; achieved HBM GB/s %peak",
-        "value": round(D ** 3 * args.steps / wall / 1e6, 1),
+        "value": round((D ** 3 if args.emulate_world <= 1 else n_slab) * args.steps / wall / 1e6, 1),
         "unit": "Mvoxels/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(wall / args.steps * 1e3, 5),
@@ -236,7 +240,7 @@ def main():
                                           "frac": round(achieved_survey / HBM_PEAK_GBS, 4)},
                      "note": "per-rank slab launch; average over the timed steps from HIP events on the launch stream"},
     }
-    if world == 1 and args.variant == 0:
+    if world == 1 and args.variant == 0 and args.emulate_world <= 1:
         # The same workload through the plain streaming variant (no elision, no summary: all 16 B per
         # updated voxel really move).  This is the kernel to read as "how close to the HBM roofline
         # does the access pattern get"; the default kernel above is faster because it moves fewer bytes.
@@ -256,7 +260,7 @@ def main():
             "value": round(D ** 3 / ms_s / 1e3, 1), "unit": "GB/s (value: Mvoxels/s)"}
         vol.set_kernel_variant(0)
         vol.reset()
-    if world == 1:
+    if world == 1 and args.emulate_world <= 1:
         # PCIe-inclusive rate of the reference-style call (tsdf_integrate: host depth pointer, staged
         # through the pinned ring, 1.2 MB H2D per frame).  Reported beside the headline, never as it.
         n_host = min(args.steps, 200)
@@ -270,7 +274,7 @@ def main():
                                    "value": round(D ** 3 * n_host / dt / 1e6, 1), "unit": "Mvoxels/s",
                                    "note": "tsdf_integrate with a host depth pointer: memcpy to pinned staging + "
                                            "H2D copy + kernel per frame, Python ctypes call overhead included"}
-    if not args.no_cpu_baseline and world == 1:
+    if not args.no_cpu_baseline and world == 1 and args.emulate_world <= 1:
         per_slice = D * D if args.workload == "sfull" else None
         base, ref = cpu_baseline(args, dims, vs, origin, cfg, depth, poses, per_slice)
         line["cpu_baseline"] = base

@@ -87,6 +87,21 @@ int tsdf_reset(tsdf_volume *vol);
  */
 int tsdf_integrate(tsdf_volume *vol, const float *depth_host, const float cam2world[16]);
 
+/*
+ * Same from the sensor's raw 16-bit frame (TUM PNG payload): copies im_height*im_width uint16
+ * (half the bytes of the float frame), converts on the device to metres with
+ * value * (1.0f / depth_factor), keeping only pixels with row % row_step == 0 and
+ * col % col_step == 0 (others become 0), then integrates.  depth_factor 5000, steps (4, 3)
+ * reproduce the offline labeller's preparation (ref: examples/label_instance_rgbd.cpp:89-100,
+ * config/TUM3.yaml:34); steps (1, 1) keep the whole frame.
+ */
+int tsdf_integrate_u16(tsdf_volume *vol, const uint16_t *raw_host, float depth_factor, int32_t row_step,
+                       int32_t col_step, const float cam2world[16]);
+
+/* The conversion alone, device to device, queued on the handle's stream. */
+int tsdf_convert_depth_u16(tsdf_volume *vol, const uint16_t *raw_dev, float *depth_dev, float depth_factor,
+                           int32_t row_step, int32_t col_step);
+
 /* Same, with the depth frame already resident in HBM on the handle's device (no copy). */
 int tsdf_integrate_device(tsdf_volume *vol, const float *depth_dev, const float cam2world[16]);
 
@@ -197,6 +212,24 @@ int tsdf_selftest_fastdiv(int32_t device, uint64_t seed, uint64_t n_samples, uin
 
 /* Select the Integrate kernel variant (0 = default; others are listed in DESIGN.md). */
 int tsdf_set_kernel_variant(tsdf_volume *vol, int32_t variant);
+
+/*
+ * Batched per-object fusion: the reference keeps one small TSDF per object instance and feeds
+ * each of them depth * (its instance mask) for every keyframe (ref: src/Engine.cpp:172-233,
+ * src/Object.cpp:67,143-166).  A batch owns n volumes (own grid, origin and base pose each; same
+ * device and image size; dim_x % 4 == 0) and integrates one frame into ALL of them with one
+ * kernel launch.  masks_dev: n device pointers to im_height*im_width {0,255} bytes (entry or
+ * whole array may be NULL = unmasked).  Volumes are borrowed with tsdf_batch_volume() for
+ * download / save / extraction; they are destroyed with the batch.
+ */
+typedef struct tsdf_batch tsdf_batch;
+int tsdf_batch_create(const tsdf_config *cfgs, int32_t n, tsdf_batch **out);
+int tsdf_batch_destroy(tsdf_batch *batch);
+int tsdf_batch_size(const tsdf_batch *batch);
+int tsdf_batch_volume(tsdf_batch *batch, int32_t i, tsdf_volume **vol);
+int tsdf_batch_integrate_device(tsdf_batch *batch, const float *depth_dev, const uint8_t *const *masks_dev,
+                                const float cam2world[16]);
+int tsdf_batch_sync(tsdf_batch *batch);
 
 /* Message describing the last failure on this thread ("" when none). */
 const char *tsdf_last_error(void);

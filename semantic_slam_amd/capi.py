@@ -16,12 +16,15 @@ LIB_PATH = os.environ.get("TSDF_HIP_LIB") or os.path.join(_PKG, "libtsdf_hip.so"
 # every symbol include/tsdf_hip.h declares (tests check the .so exports exactly these)
 ABI_SYMBOLS = [
     "tsdf_config_default", "tsdf_create", "tsdf_destroy", "tsdf_reset", "tsdf_integrate",
+    "tsdf_integrate_u16", "tsdf_convert_depth_u16",
     "tsdf_integrate_device", "tsdf_integrate_cam2base", "tsdf_integrate_masked_device",
     "tsdf_sync", "tsdf_download", "tsdf_copy_slices", "tsdf_upload", "tsdf_refresh_summary", "tsdf_device_ptrs", "tsdf_slab_voxels",
     "tsdf_get_config", "tsdf_last_cam2base", "tsdf_set_stream", "tsdf_get_stream",
     "tsdf_count_surface", "tsdf_extract_surface", "tsdf_save_ply", "tsdf_save_bin",
     "tsdf_integrate_sequence_timed", "tsdf_probe_stream", "tsdf_selftest_fastdiv", "tsdf_set_kernel_variant", "tsdf_last_error",
     "tsdf_version", "tsdf_multiply_matrix", "tsdf_invert_matrix",
+    "tsdf_batch_create", "tsdf_batch_destroy", "tsdf_batch_size", "tsdf_batch_volume",
+    "tsdf_batch_integrate_device", "tsdf_batch_sync",
 ]
 
 
@@ -59,6 +62,8 @@ def load():
     L.tsdf_destroy.argtypes = [vp]
     L.tsdf_reset.argtypes = [vp]
     L.tsdf_integrate.argtypes = [vp, vp, vp]
+    L.tsdf_integrate_u16.argtypes = [vp, vp, C.c_float, C.c_int32, C.c_int32, vp]
+    L.tsdf_convert_depth_u16.argtypes = [vp, vp, vp, C.c_float, C.c_int32, C.c_int32]
     L.tsdf_integrate_device.argtypes = [vp, vp, vp]
     L.tsdf_integrate_cam2base.argtypes = [vp, vp, vp]
     L.tsdf_integrate_masked_device.argtypes = [vp, vp, vp, vp]
@@ -87,6 +92,12 @@ def load():
     L.tsdf_multiply_matrix.argtypes = [vp, vp, vp]
     L.tsdf_multiply_matrix.restype = None
     L.tsdf_invert_matrix.argtypes = [vp, vp]
+    L.tsdf_batch_create.argtypes = [C.POINTER(TsdfConfig), C.c_int32, C.POINTER(vp)]
+    L.tsdf_batch_destroy.argtypes = [vp]
+    L.tsdf_batch_size.argtypes = [vp]
+    L.tsdf_batch_volume.argtypes = [vp, C.c_int32, C.POINTER(vp)]
+    L.tsdf_batch_integrate_device.argtypes = [vp, vp, vp, vp]
+    L.tsdf_batch_sync.argtypes = [vp]
     _lib = L
     return L
 
@@ -156,16 +167,21 @@ def selftest_fastdiv(n_samples, seed=1, device=0):
 class Volume:
     """One z-slab of a TSDF grid in HBM: thin object wrapper over the opaque C handle."""
 
-    def __init__(self, cfg):
+    def __init__(self, cfg, _borrowed_handle=None):
         self.lib = load()
         self.cfg = cfg
+        self._owned = _borrowed_handle is None
         self._h = C.c_void_p()
-        check(self.lib.tsdf_create(C.byref(cfg), C.byref(self._h)), "tsdf_create")
+        if self._owned:
+            check(self.lib.tsdf_create(C.byref(cfg), C.byref(self._h)), "tsdf_create")
+        else:
+            self._h = _borrowed_handle
 
     # -- lifetime ---------------------------------------------------------------------------
     def close(self):
         if self._h:
-            self.lib.tsdf_destroy(self._h)
+            if self._owned:
+                self.lib.tsdf_destroy(self._h)
             self._h = C.c_void_p()
 
     def __enter__(self):
@@ -201,6 +217,19 @@ class Volume:
         d = _f32(depth_host, self.cfg.im_height * self.cfg.im_width)
         p = _f32(cam2world, 16)
         check(self.lib.tsdf_integrate(self._h, d.ctypes.data, p.ctypes.data), "tsdf_integrate")
+
+    def integrate_u16(self, raw_u16, cam2world, depth_factor=5000.0, row_step=1, col_step=1):
+        """Raw 16-bit frame: half-size H2D copy, conversion (and optional subsampling) on the device."""
+        r = np.ascontiguousarray(raw_u16, dtype=np.uint16).ravel()
+        if r.size != self.cfg.im_height * self.cfg.im_width:
+            raise ValueError("raw frame size does not match the configured image")
+        p = _f32(cam2world, 16)
+        check(self.lib.tsdf_integrate_u16(self._h, r.ctypes.data, depth_factor, row_step, col_step, p.ctypes.data),
+              "tsdf_integrate_u16")
+
+    def convert_depth_u16(self, raw_ptr, depth_ptr, depth_factor=5000.0, row_step=1, col_step=1):
+        check(self.lib.tsdf_convert_depth_u16(self._h, raw_ptr, depth_ptr, depth_factor, row_step, col_step),
+              "tsdf_convert_depth_u16")
 
     def integrate_device(self, depth_ptr, cam2world):
         p = _f32(cam2world, 16)
@@ -289,3 +318,43 @@ class Volume:
 
     def save_bin(self, path):
         check(self.lib.tsdf_save_bin(self._h, os.fsencode(path)), "tsdf_save_bin")
+
+
+class Batch:
+    """n per-object volumes integrated by one launch per frame (tsdf_batch_*)."""
+
+    def __init__(self, cfgs):
+        self.lib = load()
+        self.cfgs = list(cfgs)
+        arr = (TsdfConfig * len(self.cfgs))(*self.cfgs)
+        self._h = C.c_void_p()
+        check(self.lib.tsdf_batch_create(arr, len(self.cfgs), C.byref(self._h)), "tsdf_batch_create")
+        self.volumes = []
+        for i, cfg in enumerate(self.cfgs):
+            h = C.c_void_p()
+            check(self.lib.tsdf_batch_volume(self._h, i, C.byref(h)), "tsdf_batch_volume")
+            self.volumes.append(Volume(cfg, _borrowed_handle=h))
+
+    def integrate_device(self, depth_ptr, mask_ptrs, cam2world):
+        """mask_ptrs: list of device pointers (or None entries), or None for no masks at all."""
+        p = _f32(cam2world, 16)
+        masks = None
+        if mask_ptrs is not None:
+            masks = (C.c_void_p * len(self.cfgs))(*[C.c_void_p(m) if m else C.c_void_p() for m in mask_ptrs])
+        check(self.lib.tsdf_batch_integrate_device(self._h, depth_ptr, masks, p.ctypes.data), "tsdf_batch_integrate_device")
+
+    def sync(self):
+        check(self.lib.tsdf_batch_sync(self._h), "tsdf_batch_sync")
+
+    def close(self):
+        if self._h:
+            for v in self.volumes:
+                v.close()
+            self.lib.tsdf_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

@@ -64,6 +64,7 @@ struct tsdf_volume {
     // host->device staging of depth frames
     float *h_stage[kStageSlots];
     float *d_stage[kStageSlots];
+    uint16_t *d_raw[kStageSlots];   // raw 16-bit frames (allocated on first tsdf_integrate_u16)
     hipEvent_t stage_done[kStageSlots];
     bool stage_used[kStageSlots];
     int stage_next;
@@ -76,6 +77,21 @@ struct tsdf_volume {
     // scratch for surface extraction (allocated on first use)
     void *d_scratch;
     size_t scratch_bytes;
+};
+
+// Many volumes integrated by one launch per frame (include/tsdf_hip.h, tsdf_batch_*).
+struct tsdf_batch {
+    int device;
+    std::vector<tsdf_volume *> vols;
+    hipStream_t stream;
+    // per-frame parameter blocks: pinned host ring -> device ring
+    tsdfk::IntegrateParams *h_params[kStageSlots];
+    tsdfk::IntegrateParams *d_params[kStageSlots];
+    hipEvent_t slot_done[kStageSlots];
+    bool slot_used[kStageSlots];
+    int slot_next;
+    int2 *d_slice_map;
+    int total_slices, max_bx, max_by;
 };
 
 namespace {
@@ -392,6 +408,7 @@ int tsdf_destroy(tsdf_volume *v)
         if (v->stage_done[i]) (void)hipEventDestroy(v->stage_done[i]);
         if (v->h_stage[i]) (void)hipHostFree(v->h_stage[i]);
         if (v->d_stage[i]) (void)hipFree(v->d_stage[i]);
+        if (v->d_raw[i]) (void)hipFree(v->d_raw[i]);
     }
     if (v->d_scratch) (void)hipFree(v->d_scratch);
     if (v->d_flags) (void)hipFree(v->d_flags);
@@ -421,6 +438,46 @@ int tsdf_integrate(tsdf_volume *v, const float *depth_host, const float cam2worl
     size_t img = (size_t)v->cfg.im_height * v->cfg.im_width * sizeof(float);
     std::memcpy(v->h_stage[s], depth_host, img);  // caller may free depth_host after we return
     HIP_TRY(hipMemcpyAsync(v->d_stage[s], v->h_stage[s], img, hipMemcpyHostToDevice, v->stream));
+    float c2b[16];
+    compose_cam2base(v, cam2world, c2b);
+    rc = launch_integrate(v, v->d_stage[s], nullptr, c2b);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(v->stage_done[s], v->stream));
+    v->stage_used[s] = true;
+    return TSDF_OK;
+}
+
+int tsdf_convert_depth_u16(tsdf_volume *v, const uint16_t *raw_dev, float *depth_dev, float depth_factor,
+                           int32_t row_step, int32_t col_step)
+{
+    if (!v || !raw_dev || !depth_dev) return fail(TSDF_ERR_INVALID, "tsdf_convert_depth_u16: NULL argument");
+    if (!(depth_factor > 0.0f) || row_step < 1 || col_step < 1)
+        return fail(TSDF_ERR_INVALID, "tsdf_convert_depth_u16: depth_factor must be > 0 and steps >= 1");
+    int rc = bind_device(v);
+    if (rc) return rc;
+    const int n = v->cfg.im_height * v->cfg.im_width;
+    const float scale = 1.0f / depth_factor;  // ref: examples/label_instance_rgbd.cpp:99-100 (fp32 reciprocal)
+    hipLaunchKernelGGL(tsdfk::depth_u16_to_f32, dim3((n + 255) / 256), dim3(256), 0, v->stream, raw_dev, depth_dev,
+                       v->cfg.im_height, v->cfg.im_width, scale, row_step, col_step);
+    HIP_TRY(hipGetLastError());
+    return TSDF_OK;
+}
+
+int tsdf_integrate_u16(tsdf_volume *v, const uint16_t *raw_host, float depth_factor, int32_t row_step,
+                       int32_t col_step, const float cam2world[16])
+{
+    if (!v || !raw_host || !cam2world) return fail(TSDF_ERR_INVALID, "tsdf_integrate_u16: NULL argument");
+    int rc = bind_device(v);
+    if (rc) return rc;
+    const int s = v->stage_next;
+    v->stage_next = (s + 1) % kStageSlots;
+    if (v->stage_used[s]) HIP_TRY(hipEventSynchronize(v->stage_done[s]));
+    const size_t px = (size_t)v->cfg.im_height * v->cfg.im_width;
+    if (!v->d_raw[s]) HIP_TRY(hipMalloc((void **)&v->d_raw[s], px * sizeof(uint16_t)));
+    std::memcpy(v->h_stage[s], raw_host, px * sizeof(uint16_t));  // the float-sized pinned slot holds it
+    HIP_TRY(hipMemcpyAsync(v->d_raw[s], v->h_stage[s], px * sizeof(uint16_t), hipMemcpyHostToDevice, v->stream));
+    rc = tsdf_convert_depth_u16(v, v->d_raw[s], v->d_stage[s], depth_factor, row_step, col_step);
+    if (rc) return rc;
     float c2b[16];
     compose_cam2base(v, cam2world, c2b);
     rc = launch_integrate(v, v->d_stage[s], nullptr, c2b);
@@ -650,6 +707,121 @@ int tsdf_integrate_sequence_timed(tsdf_volume *v, const float *depth_dev, const 
     if (er != hipSuccess || es != hipSuccess || et != hipSuccess)
         return fail(TSDF_ERR_HIP, "tsdf_integrate_sequence_timed: event timing failed");
     *elapsed_ms = ms;
+    return TSDF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// batched per-object volumes
+// ---------------------------------------------------------------------------------------------
+int tsdf_batch_destroy(tsdf_batch *b)
+{
+    if (!b) return TSDF_OK;
+    (void)hipSetDevice(b->device);
+    if (b->stream) (void)hipStreamSynchronize(b->stream);
+    for (tsdf_volume *v : b->vols) {
+        if (v) { v->stream = v->own_stream; tsdf_destroy(v); }
+    }
+    for (int i = 0; i < kStageSlots; ++i) {
+        if (b->h_params[i]) (void)hipHostFree(b->h_params[i]);
+        if (b->d_params[i]) (void)hipFree(b->d_params[i]);
+        if (b->slot_done[i]) (void)hipEventDestroy(b->slot_done[i]);
+    }
+    if (b->d_slice_map) (void)hipFree(b->d_slice_map);
+    if (b->stream) (void)hipStreamDestroy(b->stream);
+    delete b;
+    return TSDF_OK;
+}
+
+int tsdf_batch_create(const tsdf_config *cfgs, int32_t n, tsdf_batch **out)
+{
+    if (!cfgs || !out || n <= 0) return fail(TSDF_ERR_INVALID, "tsdf_batch_create: bad argument");
+    *out = nullptr;
+    for (int i = 0; i < n; ++i) {
+        if (cfgs[i].device != cfgs[0].device || cfgs[i].im_height != cfgs[0].im_height ||
+            cfgs[i].im_width != cfgs[0].im_width)
+            return fail(TSDF_ERR_INVALID, "tsdf_batch_create: volume %d differs in device or image size", i);
+        if (cfgs[i].dim_x % 4 != 0)
+            return fail(TSDF_ERR_INVALID, "tsdf_batch_create: volume %d: dim_x must be a multiple of 4", i);
+    }
+    tsdf_batch *b = new (std::nothrow) tsdf_batch();
+    if (!b) return fail(TSDF_ERR_INVALID, "tsdf_batch_create: out of host memory");
+    b->device = cfgs[0].device;
+    b->stream = nullptr; b->d_slice_map = nullptr; b->slot_next = 0;
+    b->total_slices = b->max_bx = b->max_by = 0;
+    for (int i = 0; i < kStageSlots; ++i) { b->h_params[i] = nullptr; b->d_params[i] = nullptr; b->slot_done[i] = nullptr; b->slot_used[i] = false; }
+    auto cleanup = [&](int code) { tsdf_batch_destroy(b); return code; };
+    std::vector<int2> map;
+    for (int i = 0; i < n; ++i) {
+        tsdf_volume *v = nullptr;
+        int rc = tsdf_create(&cfgs[i], &v);
+        if (rc) return cleanup(rc);
+        b->vols.push_back(v);
+        const int nz = cfgs[i].z_end - cfgs[i].z_begin;
+        for (int z = 0; z < nz; z += tsdfk::kBatchZ) map.push_back(make_int2(i, z));
+        b->max_bx = std::max(b->max_bx, (cfgs[i].dim_x / 4 + 63) / 64);
+        b->max_by = std::max(b->max_by, (cfgs[i].dim_y + 7) / 8);   // R = 2: 8 rows per workgroup
+    }
+    b->total_slices = (int)map.size();
+    if (b->total_slices > 65535) return cleanup(fail(TSDF_ERR_INVALID, "tsdf_batch_create: %d slice chunks in total exceed the launch limit 65535", b->total_slices));
+    hipError_t e = hipSetDevice(b->device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+    if (e == hipSuccess && !map.empty()) e = hipMalloc((void **)&b->d_slice_map, map.size() * sizeof(int2));
+    if (e == hipSuccess && !map.empty()) e = hipMemcpy(b->d_slice_map, map.data(), map.size() * sizeof(int2), hipMemcpyHostToDevice);
+    for (int i = 0; i < kStageSlots && e == hipSuccess; ++i) {
+        e = hipHostMalloc((void **)&b->h_params[i], n * sizeof(tsdfk::IntegrateParams), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc((void **)&b->d_params[i], n * sizeof(tsdfk::IntegrateParams));
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&b->slot_done[i], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) return cleanup(fail(TSDF_ERR_HIP, "tsdf_batch_create: %s", hipGetErrorString(e)));
+    for (tsdf_volume *v : b->vols) {   // creation fills ran on each volume's own stream: finish them, then share ours
+        if (hipStreamSynchronize(v->stream) != hipSuccess) return cleanup(fail(TSDF_ERR_HIP, "tsdf_batch_create: sync failed"));
+        v->stream = b->stream;
+    }
+    *out = b;
+    return TSDF_OK;
+}
+
+int tsdf_batch_size(const tsdf_batch *b) { return b ? (int)b->vols.size() : 0; }
+
+int tsdf_batch_volume(tsdf_batch *b, int32_t i, tsdf_volume **vol)
+{
+    if (!b || !vol || i < 0 || i >= (int)b->vols.size()) return fail(TSDF_ERR_INVALID, "tsdf_batch_volume: bad argument");
+    *vol = b->vols[i];
+    return TSDF_OK;
+}
+
+int tsdf_batch_sync(tsdf_batch *b)
+{
+    if (!b) return fail(TSDF_ERR_INVALID, "tsdf_batch_sync: NULL handle");
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return TSDF_OK;
+}
+
+int tsdf_batch_integrate_device(tsdf_batch *b, const float *depth_dev, const uint8_t *const *masks_dev,
+                                const float cam2world[16])
+{
+    if (!b || !depth_dev || !cam2world) return fail(TSDF_ERR_INVALID, "tsdf_batch_integrate_device: NULL argument");
+    HIP_TRY(hipSetDevice(b->device));
+    if (b->total_slices == 0) return TSDF_OK;
+    const int s = b->slot_next;
+    b->slot_next = (s + 1) % kStageSlots;
+    if (b->slot_used[s]) HIP_TRY(hipEventSynchronize(b->slot_done[s]));
+    const int n = (int)b->vols.size();
+    for (int i = 0; i < n; ++i) {
+        tsdf_volume *v = b->vols[i];
+        float c2b[16];
+        compose_cam2base(v, cam2world, c2b);   // each object has its own base frame (ref: src/Object.cpp:23-29)
+        std::memcpy(v->last_cam2base, c2b, sizeof c2b);
+        b->h_params[s][i] = make_params(v, depth_dev, masks_dev ? masks_dev[i] : nullptr, c2b, 4);
+        v->flags_known_zero = false;           // the batched kernel maintains the summary
+    }
+    HIP_TRY(hipMemcpyAsync(b->d_params[s], b->h_params[s], n * sizeof(tsdfk::IntegrateParams), hipMemcpyHostToDevice, b->stream));
+    dim3 block(64, 4, 1), grid(b->max_bx, b->max_by, b->total_slices);
+    hipLaunchKernelGGL((tsdfk::integrate_tile_batched<2, true>), grid, block, 0, b->stream, b->d_params[s], b->d_slice_map);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(b->slot_done[s], b->stream));
+    b->slot_used[s] = true;
     return TSDF_OK;
 }
 

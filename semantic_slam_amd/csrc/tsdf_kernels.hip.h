@@ -269,16 +269,17 @@ __device__ __forceinline__ bool patch_may_be_visible(const IntegrateParams &p, i
     return true;
 }
 
-template <int R, bool ELIDE, bool NT, bool MASKED, bool SUM = false, bool EARLY = false, bool FAST = false>
-__global__ __launch_bounds__(256) void integrate_tile(IntegrateParams p)
+// MASKED: 0 = plain depth, 1 = depth * (mask/255) (p.mask must be set), 2 = decided per launch
+// parameter block (p.mask may be null) -- the batched kernel, where each object brings its own.
+template <int R, bool ELIDE, bool NT, int MASKED, bool SUM, bool EARLY, bool FAST>
+__device__ __forceinline__ void integrate_tile_body(const IntegrateParams &p, const int bx, const int by, const int lz)
 {
-    const int xg = blockIdx.x * 64 + threadIdx.x;
-    const int gy0 = (blockIdx.y * 4 + threadIdx.y) * R;
-    const int lz = blockIdx.z;
+    const int xg = bx * 64 + threadIdx.x;
+    const int gy0 = (by * 4 + threadIdx.y) * R;
     if (xg >= p.xgroups || gy0 >= p.dim_y) return;
     const int gz = p.z_begin + lz;
     const size_t row0 = ((size_t)lz * p.dim_y + gy0) * (size_t)p.dim_x + (size_t)xg * 4;
-    const size_t flag0 = ((size_t)lz * p.dim_y + gy0) * (size_t)p.nseg + blockIdx.x;
+    const size_t flag0 = ((size_t)lz * p.dim_y + gy0) * (size_t)p.nseg + bx;
 
     // ---- phase 0: summary flags, and (EARLY) the speculative volume loads -----------------------
     uint32_t fl[R];
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(256) void integrate_tile(IntegrateParams p)
         have_w[r] = have_t[r] = false;
     }
     if (EARLY) {
-        const int x_first = blockIdx.x * 256;
+        const int x_first = bx * 256;
         const int x_last = min(x_first + 255, p.dim_x - 1);
         const int y_last = min(gy0 + R - 1, p.dim_y - 1);
         if (patch_may_be_visible(p, x_first, x_last, gy0, y_last, gz)) {
@@ -402,7 +403,8 @@ __global__ __launch_bounds__(256) void integrate_tile(IntegrateParams p)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float d = p.depth[pixel[r][j]];
-            if (MASKED) d = d * (p.mask[pixel[r][j]] >= 128 ? 1.0f : 0.0f);  // ref: src/Engine.cpp:192-193
+            if (MASKED == 1 || (MASKED == 2 && p.mask != nullptr))
+                d = d * (p.mask[pixel[r][j]] >= 128 ? 1.0f : 0.0f);  // ref: src/Engine.cpp:192-193
             dval[r][j] = d;
         }
     }
@@ -492,6 +494,36 @@ __global__ __launch_bounds__(256) void integrate_tile(IntegrateParams p)
     }
 }
 
+template <int R, bool ELIDE, bool NT, bool MASKED, bool SUM = false, bool EARLY = false, bool FAST = false>
+__global__ __launch_bounds__(256) void integrate_tile(IntegrateParams p)
+{
+    integrate_tile_body<R, ELIDE, NT, MASKED ? 1 : 0, SUM, EARLY, FAST>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Many volumes, one frame, one launch (the reference's real usage: one small TSDF per object
+// instance, each fed depth x its own instance mask; ref: src/Engine.cpp:172-233, src/Object.cpp:67).
+// params[] holds one parameter block per object (own grid, origin, relative pose, mask, summary);
+// chunk_map[z] = {object, first slice} for every chunk of kBatchZ consecutive slices of every
+// object, so grid = (max x-blocks, max y-blocks, total chunks); a workgroup outside its object's
+// extent leaves at once, and the parameter block (read through a wave-uniform index: scalar
+// loads) is fetched once per kBatchZ slices.
+constexpr int kBatchZ = 1;
+
+template <int R, bool NT>
+__global__ __launch_bounds__(256) void integrate_tile_batched(const IntegrateParams *__restrict__ params,
+                                                              const int2 *__restrict__ chunk_map)
+{
+    const int2 m = chunk_map[blockIdx.z];
+    const IntegrateParams p = params[m.x];
+    if constexpr (kBatchZ == 1) {
+        integrate_tile_body<R, true, NT, 2, true, false, true>(p, blockIdx.x, blockIdx.y, m.y);
+    } else {
+        const int z_end = min(m.y + kBatchZ, p.nz);
+        for (int lz = m.y; lz < z_end; ++lz)
+            integrate_tile_body<R, true, NT, 2, true, false, true>(p, blockIdx.x, blockIdx.y, lz);
+    }
+}
+
 // Device self-test of fast_div2 against the compiler's IEEE division: pseudo-random operands from a
 // counter hash, denominators in [2^-60, 2^60], numerators up to 2^60 in magnitude (plus exact
 // zeros and structured mantissas).  A sample passes when the quotients are bit-identical, or --
@@ -570,6 +602,22 @@ __global__ __launch_bounds__(256) void recompute_flags(const float *tsdf, uint32
         if (x0 + j < dim_x) ones &= __float_as_uint(tsdf[(size_t)row * dim_x + x0 + j]) == 0x3f800000u;
     const bool all = __ballot(!ones) == 0ull;
     if (threadIdx.x == 0) flags[(size_t)row * nseg + blockIdx.x] = all ? 1u : 0u;
+}
+
+// Raw 16-bit depth -> metres on the device: out = raw * scale where (row % row_step == 0 and
+// col % col_step == 0), 0 elsewhere.  scale = 1/DepthMapFactor in fp32 (5000 for TUM,
+// ref: config/TUM3.yaml:34); steps (4, 3) reproduce the offline labeller's subsampling
+// (ref: examples/label_instance_rgbd.cpp:89-100), steps (1, 1) keep every pixel.  Halves the
+// per-frame host->device copy (614 KB instead of 1.2 MB at 640x480).
+__global__ __launch_bounds__(256) void depth_u16_to_f32(const uint16_t *raw, float *out, int H, int W,
+                                                        float scale, int row_step, int col_step)
+{
+    const int n = H * W;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int r = i / W, c = i - r * W;
+        const bool keep = (r % row_step == 0) && (c % col_step == 0);
+        out[i] = (keep ? (float)raw[i] : 0.0f) * scale;
+    }
 }
 
 // TSDF = 1, weight = 0 (ref: src/tsdf.cu:79-81) written at bandwidth on the device.
