@@ -188,7 +188,7 @@ int rebuild_summary(tsdf_volume *v)
         v->flags_known_zero = false;
         return drop_summary(v);
     }
-    hipLaunchKernelGGL(tsdfk::recompute_flags, grid, block, 0, v->stream, v->d_tsdf, v->d_flags, v->cfg.dim_x, rows, v->nseg);
+    hipLaunchKernelGGL(tsdfk::recompute_flags, grid, block, 0, v->stream, v->d_tsdf, v->d_weight, v->d_flags, v->cfg.dim_x, rows, v->nseg);
     HIP_TRY(hipGetLastError());
     v->flags_known_zero = false;
     return TSDF_OK;
@@ -284,7 +284,7 @@ int fill(tsdf_volume *v)
     hipLaunchKernelGGL(tsdfk::fill_grid, dim3(blocks), dim3(256), 0, v->stream, v->d_tsdf, v->d_weight, n);
     HIP_TRY(hipGetLastError());
     if (v->n_flags) {  // every TSDF value is 1: every segment flag is set
-        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)v->d_flags, 1, v->n_flags, v->stream));
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)v->d_flags, 3, v->n_flags, v->stream));
         v->flags_known_zero = false;
     }
     return TSDF_OK;
@@ -566,8 +566,7 @@ int tsdf_upload(tsdf_volume *v, const float *tsdf_host, const float *weight_host
     if (bytes == 0) return TSDF_OK;
     if (tsdf_host) HIP_TRY(hipMemcpy(v->d_tsdf, tsdf_host, bytes, hipMemcpyHostToDevice));
     if (weight_host) HIP_TRY(hipMemcpy(v->d_weight, weight_host, bytes, hipMemcpyHostToDevice));
-    if (tsdf_host) return rebuild_summary(v);
-    return TSDF_OK;
+    return rebuild_summary(v);
 }
 
 int tsdf_refresh_summary(tsdf_volume *v)

@@ -38,8 +38,11 @@ struct IntegrateParams {
     int nz, z_begin;        // slices in this slab, global z of the first
     int H, W;
     int xgroups;            // ceil(dim_x / VX)
-    // free-space summary: one word per 256-voxel row segment, non-zero = "every TSDF value of the
-    // segment is exactly 1.0f" (true after tsdf_create/tsdf_reset); index row * nseg + segment
+    // free-space summary: one word per 256-voxel row segment (index row * nseg + segment):
+    //   bit 0 = every TSDF value of the segment is exactly 1.0f
+    //   bit 1 = every weight of the segment is finite and >= 0 (stays true under += 1)
+    // both hold after tsdf_create/tsdf_reset; bit 0 is cleared by the first update that leaves a
+    // value != 1; both are rebuilt from the arrays after tsdf_upload (recompute_flags)
     uint32_t *flags;
     int nseg;               // ceil(dim_x / 256)
     // host-proved magnitude bounds that make the shared-reciprocal projection exact (see fast_div2)
@@ -307,7 +310,7 @@ __device__ __forceinline__ void integrate_tile_body(const IntegrateParams &p, co
             }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                if (gy0 + r < p.dim_y && !(SUM && fl[r] != 0u)) {
+                if (gy0 + r < p.dim_y && !(SUM && (fl[r] & 1u))) {
                     t4[r] = vol_load<NT>(p.tsdf + row0 + (size_t)r * p.dim_x);
                     have_t[r] = true;
                 }
@@ -411,11 +414,12 @@ __device__ __forceinline__ void integrate_tile_body(const IntegrateParams &p, co
 
     // ---- phase 2: depth tests (ref: src/tsdf.cu:46-49) ------------------------------------
     float diff[R][4];
-    bool upd[R][4], rowany[R];
+    bool upd[R][4], rowany[R], bandr[R];
     bool any = false, band = false;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         rowany[r] = false;
+        bandr[r] = false;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float d = dval[r][j];
@@ -424,8 +428,9 @@ __device__ __forceinline__ void integrate_tile_body(const IntegrateParams &p, co
             const bool u = geo[r][j] && !(d <= 0.0f || d > p.max_depth) && !(df <= -p.trunc);
             upd[r][j] = u;
             rowany[r] |= u;
-            band |= u && !(df >= p.trunc);
+            bandr[r] |= u && !(df >= p.trunc);
         }
+        band |= bandr[r];
         any |= rowany[r];
     }
     if (__ballot(any) == 0ull) return;  // wavefront early-out: nothing is written
@@ -436,7 +441,7 @@ __device__ __forceinline__ void integrate_tile_body(const IntegrateParams &p, co
     for (int r = 0; r < R; ++r) {
         if (rowany[r]) {
             if (!have_w[r]) w4[r] = vol_load<NT>(p.weight + row0 + (size_t)r * p.dim_x);
-            if (!have_t[r] && !(SUM && fl[r] != 0u)) t4[r] = vol_load<NT>(p.tsdf + row0 + (size_t)r * p.dim_x);
+            if (!have_t[r] && !(SUM && (fl[r] & 1u))) t4[r] = vol_load<NT>(p.tsdf + row0 + (size_t)r * p.dim_x);
         }
     }
     float dist[R][4];
@@ -455,6 +460,18 @@ __device__ __forceinline__ void integrate_tile_body(const IntegrateParams &p, co
     // ---- phase 4: running weighted mean (ref: src/tsdf.cu:54-57), stores ----------------------
 #pragma unroll
     for (int r = 0; r < R; ++r) {
+        if (SUM && fl[r] == 3u && __ballot(bandr[r]) == 0ull) {
+            // Free space, wave-uniform: every TSDF value of the segment is 1, every weight is finite
+            // and >= 0, and every updated lane has dist == 1.  Then num = fl(1*w + 1) = fl(w + 1) = wn,
+            // the quotient is exactly 1, the TSDF row is unchanged: only the weights move.
+            if (rowany[r]) {
+                const float4 w = w4[r];
+                vol_store<NT>(p.weight + row0 + (size_t)r * p.dim_x,
+                              make_float4(upd[r][0] ? w.x + 1.0f : w.x, upd[r][1] ? w.y + 1.0f : w.y,
+                                          upd[r][2] ? w.z + 1.0f : w.z, upd[r][3] ? w.w + 1.0f : w.w));
+            }
+            continue;
+        }
         float tv[4] = {t4[r].x, t4[r].y, t4[r].z, t4[r].w};
         float wv[4] = {w4[r].x, w4[r].y, w4[r].z, w4[r].w};
         float num[4], wn[4];
@@ -483,8 +500,8 @@ __device__ __forceinline__ void integrate_tile_body(const IntegrateParams &p, co
             tv[j] = newt;
             wv[j] = upd[r][j] ? wn[j] : wv[j];
         }
-        if (SUM && fl[r] != 0u && __ballot(notone) != 0ull) {
-            if (notone) p.flags[flag0 + (size_t)r * p.nseg] = 0u;  // segment no longer all ones
+        if (SUM && (fl[r] & 1u) && __ballot(notone) != 0ull) {
+            if (notone) p.flags[flag0 + (size_t)r * p.nseg] = fl[r] & 2u;  // segment no longer all ones
         }
         const bool store_t = !ELIDE || __ballot(rowany[r] && changed) != 0ull;
         if (rowany[r]) {
@@ -591,17 +608,22 @@ __global__ __launch_bounds__(256) void stream_rmw(float *tsdf, float *weight, si
 
 // Rebuild the free-space summary from the TSDF array (after tsdf_upload or an external write):
 // one wavefront per 256-voxel row segment.  block = 64 x 4, grid = (nseg, ceil(rows/4)).
-__global__ __launch_bounds__(256) void recompute_flags(const float *tsdf, uint32_t *flags, int dim_x,
-                                                       long long n_rows, int nseg)
+__global__ __launch_bounds__(256) void recompute_flags(const float *tsdf, const float *weight, uint32_t *flags,
+                                                       int dim_x, long long n_rows, int nseg)
 {
     const long long row = (long long)blockIdx.y * 4 + threadIdx.y;
     if (row >= n_rows) return;
     const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    bool ones = true;
-    for (int j = 0; j < 4; ++j)
-        if (x0 + j < dim_x) ones &= __float_as_uint(tsdf[(size_t)row * dim_x + x0 + j]) == 0x3f800000u;
-    const bool all = __ballot(!ones) == 0ull;
-    if (threadIdx.x == 0) flags[(size_t)row * nseg + blockIdx.x] = all ? 1u : 0u;
+    bool ones = true, sane = true;
+    for (int j = 0; j < 4; ++j) {
+        if (x0 + j < dim_x) {
+            ones &= __float_as_uint(tsdf[(size_t)row * dim_x + x0 + j]) == 0x3f800000u;
+            const float w = weight[(size_t)row * dim_x + x0 + j];
+            sane &= (w >= 0.0f) && (w < 3.0e38f);
+        }
+    }
+    const uint32_t f = (__ballot(!ones) == 0ull ? 1u : 0u) | (__ballot(!sane) == 0ull ? 2u : 0u);
+    if (threadIdx.x == 0) flags[(size_t)row * nseg + blockIdx.x] = f;
 }
 
 // Raw 16-bit depth -> metres on the device: out = raw * scale where (row % row_step == 0 and

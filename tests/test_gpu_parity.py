@@ -138,7 +138,25 @@ def test_free_space_summary_stays_consistent(cuda, oracle):
         step(scene.depth(p0), p0, 39)
         t, w = vol.download()
         assert_parity(t, w, ref_t, ref_w)
-    assert np.count_nonzero(ref_t != 1.0) > 1000
+        assert np.count_nonzero(ref_t != 1.0) > 1000
+        # weights no counter can reach (-1 makes w+1 == 0, inf, huge): the free-space shortcut must
+        # not be taken for their segments; values (NaN included) must still equal the oracle's
+        vol.reset()
+        ref_t[:], ref_w[:] = 1.0, 0.0
+        w_odd = ref_w.copy()
+        w_odd[5::4099] = -1.0
+        w_odd[7::5003] = np.inf
+        w_odd[11::6007] = 3.3e38
+        w_odd[13::7001] = -0.5
+        vol.upload(ref_t, w_odd)
+        ref_w[:] = w_odd
+        with np.errstate(all="ignore"):
+            step(far, p0, 0)
+            step(far, p1, 0)
+        t, w = vol.download()
+        assert np.array_equal(w, ref_w, equal_nan=True)
+        assert np.array_equal(t, ref_t, equal_nan=True)
+        assert np.isnan(ref_t).sum() > 0 and np.isfinite(ref_t).sum() > 0
 
 
 def test_host_depth_path_equals_device_path(cuda, oracle):
