@@ -112,6 +112,17 @@ int tsdf_integrate_device(tsdf_volume *vol, const float *depth_dev, const float 
 int tsdf_integrate_cam2base(tsdf_volume *vol, const float *depth_dev, const float cam2base[16]);
 
 /*
+ * A known sequence of frames (offline replay of saved keyframes, ref:
+ * examples/label_instance_rgbd.cpp:78-110): exactly n_frames consecutive tsdf_integrate_device /
+ * tsdf_integrate_masked_device calls -- same results, bit for bit -- but the library may apply
+ * several frames per pass over the volume (weights read and written once per group).
+ * depth_dev: n_frames device pointers; masks_dev: NULL or n_frames device pointers (entries may be
+ * NULL); cam2world: n_frames x 16 floats.
+ */
+int tsdf_integrate_frames_device(tsdf_volume *vol, const float *const *depth_dev, const uint8_t *const *masks_dev,
+                                 const float *cam2world, int32_t n_frames);
+
+/*
  * Per-instance fusion as the reference's caller prepares it: depth * (mask/255) with an
  * 8-bit {0,255} instance mask (ref: src/Engine.cpp:192-193), fused into the depth load
  * instead of materialising the masked image.  mask_dev: im_height*im_width bytes in HBM.

@@ -18,6 +18,7 @@ ABI_SYMBOLS = [
     "tsdf_config_default", "tsdf_create", "tsdf_destroy", "tsdf_reset", "tsdf_integrate",
     "tsdf_integrate_u16", "tsdf_convert_depth_u16",
     "tsdf_integrate_device", "tsdf_integrate_cam2base", "tsdf_integrate_masked_device",
+    "tsdf_integrate_frames_device",
     "tsdf_sync", "tsdf_download", "tsdf_copy_slices", "tsdf_upload", "tsdf_refresh_summary", "tsdf_device_ptrs", "tsdf_slab_voxels",
     "tsdf_get_config", "tsdf_last_cam2base", "tsdf_set_stream", "tsdf_get_stream",
     "tsdf_count_surface", "tsdf_extract_surface", "tsdf_save_ply", "tsdf_save_bin",
@@ -67,6 +68,7 @@ def load():
     L.tsdf_integrate_device.argtypes = [vp, vp, vp]
     L.tsdf_integrate_cam2base.argtypes = [vp, vp, vp]
     L.tsdf_integrate_masked_device.argtypes = [vp, vp, vp, vp]
+    L.tsdf_integrate_frames_device.argtypes = [vp, vp, vp, vp, C.c_int32]
     L.tsdf_sync.argtypes = [vp]
     L.tsdf_download.argtypes = [vp, vp, vp]
     L.tsdf_upload.argtypes = [vp, vp, vp]
@@ -243,6 +245,17 @@ class Volume:
         p = _f32(cam2world, 16)
         check(self.lib.tsdf_integrate_masked_device(self._h, depth_ptr, mask_ptr, p.ctypes.data),
               "tsdf_integrate_masked_device")
+
+    def integrate_frames_device(self, depth_ptrs, poses, mask_ptrs=None):
+        """A known sequence of frames == that many integrate_device calls, possibly fused per launch."""
+        p = _f32(np.asarray(poses, dtype=np.float32))
+        n = p.size // 16
+        assert len(depth_ptrs) == n
+        d = (C.c_void_p * n)(*[C.c_void_p(x) for x in depth_ptrs])
+        m = None
+        if mask_ptrs is not None:
+            m = (C.c_void_p * n)(*[C.c_void_p(x) if x else C.c_void_p() for x in mask_ptrs])
+        check(self.lib.tsdf_integrate_frames_device(self._h, d, m, p.ctypes.data, n), "tsdf_integrate_frames_device")
 
     def integrate_sequence_timed(self, depth_ptr, poses):
         """Queue len(poses) frames back to back; returns device milliseconds (HIP events)."""

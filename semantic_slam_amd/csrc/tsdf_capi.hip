@@ -23,6 +23,7 @@
 
 #include "pose_math.h"
 #include "tsdf_kernels.hip.h"
+#include "tsdf_multiframe.hip.h"
 #include "tsdf_extract.hip.h"
 
 namespace {
@@ -69,6 +70,12 @@ struct tsdf_volume {
     bool stage_used[kStageSlots];
     int stage_next;
     int variant;
+    // per-launch frame blocks of integrate_multi: pinned host ring -> device ring (allocated on first use)
+    tsdfk::FramePose *h_frames[kStageSlots];
+    tsdfk::FramePose *d_frames[kStageSlots];
+    hipEvent_t frames_done[kStageSlots];
+    bool frames_used[kStageSlots];
+    int frames_next;
     // free-space summary (one word per 256-voxel row segment), see tsdf_kernels.hip.h
     uint32_t *d_flags;
     size_t n_flags;
@@ -150,7 +157,11 @@ tsdfk::IntegrateParams make_params(const tsdf_volume *v, const float *depth_dev,
 }
 
 // Kernel variants (tsdf_set_kernel_variant):
-//   0        default: integrate_tile<2, elide, nt> when dim_x % 4 == 0, else the scalar kernel
+//   0        default: integrate_tile<2, elide, nt, summary, fast> when dim_x % 4 == 0, else the scalar
+//            kernel; frame sequences (tsdf_integrate_frames_device, ..._sequence_timed) go through
+//            integrate_multi, up to 4 frames per pass over the volume
+//   3        as 0 but one launch per frame even for sequences
+//   4        as 0 with integrate_multi<R=2> (experiment; the default fuses with R=1)
 //   1        scalar kernel integrate_rows<1> (any dim_x)
 //   2        first version integrate_rows<4> (one row per wavefront, no elision)
 //   16 + c   experiments: c = (rsel << 2) | (elide << 1) | nt, R = 1, 2, 4 for rsel = 0, 1, 2
@@ -204,7 +215,7 @@ int launch_integrate(tsdf_volume *v, const float *depth_dev, const uint8_t *mask
     if (nz == 0) return TSDF_OK;  // empty slab: nothing to do
     std::memcpy(v->last_cam2base, c2b, sizeof v->last_cam2base);
     int variant = v->variant;
-    if (variant == 0) variant = kDefaultTile;
+    if (variant == 0 || variant == 3 || variant == 4) variant = kDefaultTile;
     if (c.dim_x % 4 != 0) variant = 1;  // rows are not 16-byte aligned: scalar kernel
     const int vx = variant == 1 ? 1 : 4;
     tsdfk::IntegrateParams p = make_params(v, depth_dev, mask_dev, c2b, vx);
@@ -273,6 +284,70 @@ int launch_integrate(tsdf_volume *v, const float *depth_dev, const uint8_t *mask
 void compose_cam2base(const tsdf_volume *v, const float *cam2world, float *c2b)
 {
     tsdf_host::multiply_matrix(v->base2world_inv, cam2world, c2b);  // ref: src/tsdf.cu:142
+}
+
+// n frames (n <= kMaxFramesPerLaunch) in one pass over the slab.  c2b: n x 16 relative poses.
+int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *const *masks_dev,
+                 const float *c2b, int n)
+{
+    const tsdf_config &c = v->cfg;
+    const int nz = c.z_end - c.z_begin;
+    if (nz == 0 || n == 0) return TSDF_OK;
+    const int s = v->frames_next;
+    v->frames_next = (s + 1) % kStageSlots;
+    const size_t bytes = tsdfk::kMaxFramesPerLaunch * sizeof(tsdfk::FramePose);
+    if (!v->h_frames[s]) {
+        HIP_TRY(hipHostMalloc((void **)&v->h_frames[s], bytes, hipHostMallocDefault));
+        HIP_TRY(hipMalloc((void **)&v->d_frames[s], bytes));
+        HIP_TRY(hipEventCreateWithFlags(&v->frames_done[s], hipEventDisableTiming));
+    }
+    if (v->frames_used[s]) HIP_TRY(hipEventSynchronize(v->frames_done[s]));
+    tsdfk::MultiParams mp;
+    mp.common = make_params(v, depth_dev[0], nullptr, c2b, 4);
+    mp.frames = v->d_frames[s];
+    mp.n_frames = n;
+    for (int f = 0; f < n; ++f) {
+        const tsdfk::IntegrateParams q = make_params(v, depth_dev[f], masks_dev ? masks_dev[f] : nullptr, c2b + 16 * f, 4);
+        tsdfk::FramePose &fp = v->h_frames[s][f];
+        fp.depth = q.depth; fp.mask = q.mask;
+        fp.rx0 = q.rx0; fp.rx1 = q.rx1; fp.rx2 = q.rx2;
+        fp.ry0 = q.ry0; fp.ry1 = q.ry1; fp.ry2 = q.ry2;
+        fp.rz0 = q.rz0; fp.rz1 = q.rz1; fp.rz2 = q.rz2;
+        fp.tx = q.tx; fp.ty = q.ty; fp.tz = q.tz;
+        fp.fast_ok = q.fast_ok; fp.pad_ = 0;
+    }
+    HIP_TRY(hipMemcpyAsync(v->d_frames[s], v->h_frames[s], n * sizeof(tsdfk::FramePose), hipMemcpyHostToDevice, v->stream));
+    std::memcpy(v->last_cam2base, c2b + 16 * (n - 1), sizeof v->last_cam2base);
+    v->flags_known_zero = false;   // integrate_multi maintains the summary
+    dim3 block(64, 4, 1);
+    if (v->variant == 4) {   // experiment: two rows per lane
+        dim3 grid((mp.common.xgroups + 63) / 64, (c.dim_y + 7) / 8, nz);
+        hipLaunchKernelGGL((tsdfk::integrate_multi<2, true>), grid, block, 0, v->stream, mp);
+    } else {
+        dim3 grid((mp.common.xgroups + 63) / 64, (c.dim_y + 3) / 4, nz);
+        hipLaunchKernelGGL((tsdfk::integrate_multi<1, true>), grid, block, 0, v->stream, mp);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(v->frames_done[s], v->stream));
+    v->frames_used[s] = true;
+    return TSDF_OK;
+}
+
+// A sequence of frames: fused kMaxFramesPerLaunch at a time when the default kernel is selected.
+int integrate_frames(tsdf_volume *v, const float *const *depth_dev, const uint8_t *const *masks_dev,
+                     const float *cam2world, int n_frames)
+{
+    const bool fuse = (v->variant == 0 || v->variant == 4) && v->cfg.dim_x % 4 == 0;
+    int rc = TSDF_OK;
+    for (int k = 0; k < n_frames && rc == TSDF_OK;) {
+        const int n = fuse ? std::min(tsdfk::kMaxFramesPerLaunch, n_frames - k) : 1;
+        float c2b[16 * tsdfk::kMaxFramesPerLaunch];
+        for (int i = 0; i < n; ++i) compose_cam2base(v, cam2world + 16 * (k + i), c2b + 16 * i);
+        if (fuse) rc = launch_multi(v, depth_dev + k, masks_dev ? masks_dev + k : nullptr, c2b, n);
+        else rc = launch_integrate(v, depth_dev[k], masks_dev ? masks_dev[k] : nullptr, c2b);
+        k += n;
+    }
+    return rc;
 }
 
 int fill(tsdf_volume *v)
@@ -410,6 +485,11 @@ int tsdf_destroy(tsdf_volume *v)
         if (v->d_stage[i]) (void)hipFree(v->d_stage[i]);
         if (v->d_raw[i]) (void)hipFree(v->d_raw[i]);
     }
+    for (int i = 0; i < kStageSlots; ++i) {
+        if (v->h_frames[i]) (void)hipHostFree(v->h_frames[i]);
+        if (v->d_frames[i]) (void)hipFree(v->d_frames[i]);
+        if (v->frames_done[i]) (void)hipEventDestroy(v->frames_done[i]);
+    }
     if (v->d_scratch) (void)hipFree(v->d_scratch);
     if (v->d_flags) (void)hipFree(v->d_flags);
     if (v->d_tsdf) (void)hipFree(v->d_tsdf);
@@ -503,6 +583,18 @@ int tsdf_integrate_cam2base(tsdf_volume *v, const float *depth_dev, const float 
     int rc = bind_device(v);
     if (rc) return rc;
     return launch_integrate(v, depth_dev, nullptr, cam2base);
+}
+
+int tsdf_integrate_frames_device(tsdf_volume *v, const float *const *depth_dev, const uint8_t *const *masks_dev,
+                                 const float *cam2world, int32_t n_frames)
+{
+    if (!v || !depth_dev || !cam2world || n_frames < 0)
+        return fail(TSDF_ERR_INVALID, "tsdf_integrate_frames_device: bad argument");
+    for (int k = 0; k < n_frames; ++k)
+        if (!depth_dev[k]) return fail(TSDF_ERR_INVALID, "tsdf_integrate_frames_device: depth_dev[%d] is NULL", k);
+    int rc = bind_device(v);
+    if (rc) return rc;
+    return integrate_frames(v, depth_dev, masks_dev, cam2world, n_frames);
 }
 
 int tsdf_integrate_masked_device(tsdf_volume *v, const float *depth_dev, const uint8_t *mask_dev,
@@ -623,7 +715,7 @@ int tsdf_set_kernel_variant(tsdf_volume *v, int32_t variant)
     if (!v) return fail(TSDF_ERR_INVALID, "tsdf_set_kernel_variant: NULL handle");
     const int c = (variant - 32) & 15;
     const bool sum_ok = variant >= 32 && variant < 112 && c < 12 && ((c >> 1) & 1);
-    if (!(variant >= 0 && variant <= 2) && !(variant >= 16 && variant < 28) && !sum_ok)
+    if (!(variant >= 0 && variant <= 4) && !(variant >= 16 && variant < 28) && !sum_ok)
         return fail(TSDF_ERR_INVALID, "tsdf_set_kernel_variant: unknown variant %d", variant);
     v->variant = variant;
     return TSDF_OK;
@@ -691,10 +783,9 @@ int tsdf_integrate_sequence_timed(tsdf_volume *v, const float *depth_dev, const 
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, v->stream));
-    for (int k = 0; k < n_frames && rc == TSDF_OK; ++k) {
-        float c2b[16];
-        compose_cam2base(v, cam2world + 16 * k, c2b);
-        rc = launch_integrate(v, depth_dev, nullptr, c2b);
+    {
+        std::vector<const float *> depths((size_t)n_frames, depth_dev);
+        rc = integrate_frames(v, depths.data(), nullptr, cam2world, n_frames);
     }
     hipError_t er = hipEventRecord(e1, v->stream);
     hipError_t es = hipEventSynchronize(e1);

@@ -1,0 +1,253 @@
+// tsdf_multiframe.hip.h -- several frames per pass over the volume.
+//
+// Integrating frame after frame reads and writes every touched weight once per frame.  When the
+// frames are known together (offline labelling replays saved keyframes: ref
+// examples/label_instance_rgbd.cpp:78-110; bench sequences), a lane can keep its voxels in
+// registers and apply F frames to them in order: the volume is read once and written once per F
+// frames, the launch and its fill/drain are paid once per F frames, and the pose-independent part
+// of the geometry is shared.  Every voxel sees exactly the same sequence of updates as with F
+// separate launches, so the result is bit-identical (tests/test_gpu_multiframe.py).
+//
+// Structure per wavefront (256(x) x R(y) voxels of one slice, as integrate_tile):
+//   flags -> for f in frames { geometry(f), depth gather(f), tests(f); first touching frame loads
+//   the quads; update in registers } -> store weights / changed TSDF rows / cleared flag.
+// The per-frame arithmetic is the FAST + ELIDE + SUM path of integrate_tile (same helpers).
+#pragma once
+#include "tsdf_kernels.hip.h"
+
+namespace tsdfk {
+
+constexpr int kMaxFramesPerLaunch = 4;
+
+struct FramePose {
+    const float *depth;
+    const uint8_t *mask;     // may be null
+    float rx0, rx1, rx2, ry0, ry1, ry2, rz0, rz1, rz2, tx, ty, tz;   // as IntegrateParams
+    int fast_ok;
+    int pad_;
+};
+
+struct MultiParams {
+    IntegrateParams common;   // grid, intrinsics, volume pointers, summary; its pose fields are unused
+    const FramePose *frames;  // n_frames blocks in device memory (indexed in a loop: a by-value array
+    int n_frames;             // in the kernarg would be copied to registers and selected per frame)
+};
+
+template <int R, bool NT>
+__global__ __launch_bounds__(256) void integrate_multi(MultiParams mp)
+{
+    const IntegrateParams &p = mp.common;
+    const int bx = blockIdx.x, lz = blockIdx.z;
+    const int xg = bx * 64 + threadIdx.x;
+    const int gy0 = (blockIdx.y * 4 + threadIdx.y) * R;
+    if (xg >= p.xgroups || gy0 >= p.dim_y) return;
+    const int gz = p.z_begin + lz;
+    const size_t row0 = ((size_t)lz * p.dim_y + gy0) * (size_t)p.dim_x + (size_t)xg * 4;
+    const size_t flag0 = ((size_t)lz * p.dim_y + gy0) * (size_t)p.nseg + bx;
+
+    // ---- voxel state held in registers across the frames ----------------------------------------
+    uint32_t fl[R];
+    bool ones[R];            // wave-uniform: every TSDF value of the row segment is (still) exactly 1
+    float4 t4[R], w4[R];
+    bool touched[R], tchanged[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        fl[r] = gy0 + r < p.dim_y ? p.flags[flag0 + (size_t)r * p.nseg] : 0u;
+        ones[r] = (fl[r] & 1u) != 0u;
+        t4[r] = make_float4(1.f, 1.f, 1.f, 1.f);
+        w4[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        touched[r] = tchanged[r] = false;
+    }
+
+    // pose-independent voxel coordinates (ref: src/tsdf.cu:27-29)
+    float bxv[4], byv[R];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bxv[j] = p.ox + (float)(xg * 4 + j) * p.vs;
+#pragma unroll
+    for (int r = 0; r < R; ++r) byv[r] = p.oy + (float)(gy0 + r) * p.vs;
+    const float bz = p.oz + (float)gz * p.vs;
+    const v2f F = {p.fx, p.fy}, C = {p.cx, p.cy};
+
+    // not unrolled: one frame's temporaries at a time (unrolling interleaves frames: 100 VGPRs)
+#pragma unroll 1
+    for (int f = 0; f < mp.n_frames; ++f) {
+        const FramePose q = mp.frames[f];   // wave-uniform address: scalar loads
+
+        // ---- geometry of frame f (ref: src/tsdf.cu:33-43) ------------------------------------------
+        float ax[4], ay[4], az[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float dx = bxv[j] - q.tx;
+            ax[j] = q.rx0 * dx; ay[j] = q.ry0 * dx; az[j] = q.rz0 * dx;
+        }
+        const float dz = bz - q.tz;
+        const float x2 = q.rx2 * dz, y2 = q.ry2 * dz, z2 = q.rz2 * dz;
+        float pcz[R][4], dval[R][4];
+        bool geo[R][4];
+        int pixel[R][4];
+        bool unsafe = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float z1 = q.rz1 * (byv[r] - q.ty);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float cz = az[j] + z1 + z2;
+                pcz[r][j] = cz;
+                unsafe |= cz > 0.0f && cz < TSDF_FAST_D_MIN;
+            }
+        }
+        if (q.fast_ok != 0 && __ballot(unsafe) == 0ull) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const bool row_ok = gy0 + r < p.dim_y;
+                const float dy = byv[r] - q.ty;
+                const v2f XY1 = {q.rx1 * dy, q.ry1 * dy};
+                const v2f XY2 = {x2, y2};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const v2f A = {ax[j], ay[j]};
+                    const v2f n = A + XY1 + XY2;
+                    const float cz = pcz[r][j];
+                    const v2f uv = F * fast_div2(n, cz) + C;
+                    const v2f tr = {__builtin_truncf(uv.x), __builtin_truncf(uv.y)};
+                    const v2f fr = uv - tr;
+                    const v2f rd = {tr.x + (fr.x >= 0.5f ? 1.0f : 0.0f), tr.y + (fr.y >= 0.5f ? 1.0f : 0.0f)};
+                    const bool ok = row_ok && cz > 0.0f && uv.x > -0.5f && uv.y > -0.5f && rd.x < (float)p.W &&
+                                    rd.y < (float)p.H;
+                    geo[r][j] = ok;
+                    pixel[r][j] = ok ? (int)rd.y * p.W + (int)rd.x : 0;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const bool row_ok = gy0 + r < p.dim_y;
+                const float dy = byv[r] - q.ty;
+                const float x1 = q.rx1 * dy, y1 = q.ry1 * dy;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float cx = ax[j] + x1 + x2;
+                    const float cy = ay[j] + y1 + y2;
+                    const float cz = pcz[r][j];
+                    const float pu = roundf(p.fx * (cx / cz) + p.cx);
+                    const float pv = roundf(p.fy * (cy / cz) + p.cy);
+                    const bool ok = row_ok && !(cz <= 0.0f) && pu >= 0.0f && pu < (float)p.W && pv >= 0.0f &&
+                                    pv < (float)p.H;
+                    geo[r][j] = ok;
+                    pixel[r][j] = ok ? (int)pv * p.W + (int)pu : 0;
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float d = q.depth[pixel[r][j]];
+                if (q.mask != nullptr) d = d * (q.mask[pixel[r][j]] >= 128 ? 1.0f : 0.0f);  // ref: src/Engine.cpp:192-193
+                dval[r][j] = d;
+            }
+        }
+
+        // ---- depth tests (ref: src/tsdf.cu:46-49) ----------------------------------------------------
+        float diff[R][4];
+        bool upd[R][4], rowany[R], bandr[R];
+        bool any = false, band = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            rowany[r] = false;
+            bandr[r] = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = dval[r][j];
+                const float df = d - pcz[r][j];
+                diff[r][j] = df;
+                const bool u = geo[r][j] && !(d <= 0.0f || d > p.max_depth) && !(df <= -p.trunc);
+                upd[r][j] = u;
+                rowany[r] |= u;
+                bandr[r] |= u && !(df >= p.trunc);
+            }
+            band |= bandr[r];
+            any |= rowany[r];
+        }
+        if (__ballot(any) == 0ull) continue;   // this frame touches nothing here
+
+        // ---- first touch: bring the quads in -------------------------------------------------------
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (rowany[r] && !touched[r]) {
+                w4[r] = vol_load<NT>(p.weight + row0 + (size_t)r * p.dim_x);
+                if (!(fl[r] & 1u)) t4[r] = vol_load<NT>(p.tsdf + row0 + (size_t)r * p.dim_x);
+                touched[r] = true;
+            }
+        }
+        float dist[R][4];
+        if (__ballot(band) != 0ull) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dist[r][j] = fminf(1.0f, diff[r][j] / p.trunc);  // ref: :53
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dist[r][j] = 1.0f;
+        }
+
+        // ---- update in registers (ref: src/tsdf.cu:54-57) ----------------------------------------------
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (ones[r] && (fl[r] & 2u) && __ballot(bandr[r]) == 0ull) {
+                // free space (see integrate_tile): the TSDF row stays 1, only the weights move
+                if (upd[r][0]) w4[r].x += 1.0f;
+                if (upd[r][1]) w4[r].y += 1.0f;
+                if (upd[r][2]) w4[r].z += 1.0f;
+                if (upd[r][3]) w4[r].w += 1.0f;
+                continue;
+            }
+            float tv[4] = {t4[r].x, t4[r].y, t4[r].z, t4[r].w};
+            float wv[4] = {w4[r].x, w4[r].y, w4[r].z, w4[r].w};
+            float num[4], wn[4];
+            bool need = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                wn[j] = wv[j] + 1.0f;
+                num[j] = tv[j] * wv[j] + dist[r][j];
+                need |= upd[r][j] && !(num[j] == wn[j] && wn[j] < 3.0e38f && wn[j] > 0.0f);
+            }
+            float nt[4];
+            if (__ballot(rowany[r] && need) != 0ull) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) nt[j] = num[j] / wn[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) nt[j] = 1.0f;
+            }
+            bool changed = false, notone = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float newt = upd[r][j] ? nt[j] : tv[j];
+                changed |= __float_as_uint(newt) != __float_as_uint(tv[j]);
+                notone |= upd[r][j] && __float_as_uint(newt) != 0x3f800000u;
+                tv[j] = newt;
+                wv[j] = upd[r][j] ? wn[j] : wv[j];
+            }
+            t4[r] = make_float4(tv[0], tv[1], tv[2], tv[3]);
+            w4[r] = make_float4(wv[0], wv[1], wv[2], wv[3]);
+            tchanged[r] |= changed;
+            if (__ballot(notone) != 0ull) ones[r] = false;   // for every lane of the wavefront
+        }
+    }
+
+    // ---- write back ------------------------------------------------------------------------------------
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const bool store_t = __ballot(touched[r] && tchanged[r]) != 0ull;
+        if (touched[r]) {
+            if (store_t) vol_store<NT>(p.tsdf + row0 + (size_t)r * p.dim_x, t4[r]);
+            vol_store<NT>(p.weight + row0 + (size_t)r * p.dim_x, w4[r]);
+        }
+        if ((fl[r] & 1u) && !ones[r]) p.flags[flag0 + (size_t)r * p.nseg] = fl[r] & 2u;
+    }
+}
+
+}  // namespace tsdfk

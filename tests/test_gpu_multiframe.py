@@ -1,0 +1,51 @@
+"""Several frames per pass over the volume (tsdf_integrate_frames_device -> integrate_multi) must equal
+the same frames integrated one launch at a time -- which the oracle pins -- bit for bit."""
+import numpy as np
+import pytest
+
+from semantic_slam_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("variant", [0, 4, 3])
+@pytest.mark.parametrize("n_frames", [1, 3, 4, 9])
+def test_fused_frames_equal_sequential_and_oracle(cuda, oracle, n_frames, variant):
+    dims, vs = (256, 42, 30), 0.008          # ragged row groups for R = 1 and R = 2
+    origin = synth.surf_volume(256, vs, 0.6)
+    cfg = capi.make_config(dims, vs, origin)
+    scene = synth.SurfScene(dims, vs, origin)
+    rng = np.random.default_rng(n_frames)
+    frames, keep = [], []
+    for k in range(n_frames):
+        c2w = scene.pose(k % 5, n=7)          # repeats: weights > 1 on non-trivial TSDF values
+        if k % 3 == 2:
+            depth = np.full((480, 640), 5.9, np.float32)   # a pure free-space frame in the middle
+        else:
+            depth = scene.depth(c2w, quantize=True)
+        mask = None
+        if k % 4 == 1:
+            mask = np.zeros((480, 640), np.uint8)
+            mask[rng.integers(50, 150):rng.integers(300, 450), rng.integers(50, 200):rng.integers(400, 600)] = 255
+        frames.append((c2w, depth, mask))
+    ref_t, ref_w = oracle.init_grid(dims)
+    for c2w, depth, mask in frames:
+        d = depth if mask is None else oracle.mask_depth(depth, mask)
+        oracle.integrate(cfg.cam_K, c2w, d, dims, origin, vs, cfg.trunc_margin, ref_t, ref_w)
+    with capi.Volume(cfg) as vol:
+        vol.set_kernel_variant(variant)
+        for c2w, depth, mask in frames:
+            keep.append((cuda.from_numpy(depth).cuda(), None if mask is None else cuda.from_numpy(mask).cuda()))
+        vol.integrate_frames_device([d.data_ptr() for d, _ in keep], np.stack([f[0] for f in frames]),
+                                    [None if m is None else m.data_ptr() for _, m in keep])
+        t, w = vol.download()
+        assert np.array_equal(w, ref_w) and np.array_equal(t.view(np.uint32), ref_t.view(np.uint32))
+        # and a second batch on top of the first (state carried through memory + summary)
+        vol.integrate_frames_device([d.data_ptr() for d, _ in keep][:2], np.stack([f[0] for f in frames[:2]]),
+                                    [None if m is None else m.data_ptr() for _, m in keep][:2])
+        for c2w, depth, mask in frames[:2]:
+            d = depth if mask is None else oracle.mask_depth(depth, mask)
+            oracle.integrate(cfg.cam_K, c2w, d, dims, origin, vs, cfg.trunc_margin, ref_t, ref_w)
+        t, w = vol.download()
+    assert ref_w.max() >= 2 or n_frames == 1
+    assert np.array_equal(w, ref_w) and np.array_equal(t.view(np.uint32), ref_t.view(np.uint32))
