@@ -405,9 +405,11 @@ __device__ __forceinline__ void integrate_tile_body(const IntegrateParams &p, co
     for (int r = 0; r < R; ++r) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float d = p.depth[pixel[r][j]];
+            // unsigned 32-bit offset from a wave-uniform base: the load takes the base from SGPRs
+            const uint32_t px = (uint32_t)pixel[r][j];
+            float d = p.depth[px];
             if (MASKED == 1 || (MASKED == 2 && p.mask != nullptr))
-                d = d * (p.mask[pixel[r][j]] >= 128 ? 1.0f : 0.0f);  // ref: src/Engine.cpp:192-193
+                d = d * (p.mask[px] >= 128 ? 1.0f : 0.0f);  // ref: src/Engine.cpp:192-193
             dval[r][j] = d;
         }
     }
@@ -425,10 +427,11 @@ __device__ __forceinline__ void integrate_tile_body(const IntegrateParams &p, co
             const float d = dval[r][j];
             const float df = d - pcz[r][j];
             diff[r][j] = df;
-            const bool u = geo[r][j] && !(d <= 0.0f || d > p.max_depth) && !(df <= -p.trunc);
+            // bitwise, not short-circuit: four compares and mask logic, no exec-mask regions
+            const bool u = geo[r][j] & !((d <= 0.0f) | (d > p.max_depth)) & !(df <= -p.trunc);
             upd[r][j] = u;
             rowany[r] |= u;
-            bandr[r] |= u && !(df >= p.trunc);
+            bandr[r] |= u & !(df >= p.trunc);
         }
         band |= bandr[r];
         any |= rowany[r];

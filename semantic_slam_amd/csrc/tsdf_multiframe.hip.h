@@ -142,8 +142,9 @@ __global__ __launch_bounds__(256) void integrate_multi(MultiParams mp)
         for (int r = 0; r < R; ++r) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float d = q.depth[pixel[r][j]];
-                if (q.mask != nullptr) d = d * (q.mask[pixel[r][j]] >= 128 ? 1.0f : 0.0f);  // ref: src/Engine.cpp:192-193
+                const uint32_t px = (uint32_t)pixel[r][j];
+                float d = q.depth[px];
+                if (q.mask != nullptr) d = d * (q.mask[px] >= 128 ? 1.0f : 0.0f);  // ref: src/Engine.cpp:192-193
                 dval[r][j] = d;
             }
         }
@@ -161,10 +162,10 @@ __global__ __launch_bounds__(256) void integrate_multi(MultiParams mp)
                 const float d = dval[r][j];
                 const float df = d - pcz[r][j];
                 diff[r][j] = df;
-                const bool u = geo[r][j] && !(d <= 0.0f || d > p.max_depth) && !(df <= -p.trunc);
+                const bool u = geo[r][j] & !((d <= 0.0f) | (d > p.max_depth)) & !(df <= -p.trunc);
                 upd[r][j] = u;
                 rowany[r] |= u;
-                bandr[r] |= u && !(df >= p.trunc);
+                bandr[r] |= u & !(df >= p.trunc);
             }
             band |= bandr[r];
             any |= rowany[r];
