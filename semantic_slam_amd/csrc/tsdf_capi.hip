@@ -143,14 +143,18 @@ tsdfk::IntegrateParams make_params(const tsdf_volume *v, const float *depth_dev,
         for (int k = 0; k < 3; ++k) dmax[k] = std::fmax(std::fabs(o[k] - t[k]), std::fabs(o[k] + ext[k] - t[k])) * 1.001 + 1e-30;
         const double rows[3][3] = {{p.rx0, p.rx1, p.rx2}, {p.ry0, p.ry1, p.ry2}, {p.rz0, p.rz1, p.rz2}};
         bool ok = true;
+        double bz = 0;
         for (int i = 0; i < 3; ++i) {
             double b = 0;
             for (int k = 0; k < 3; ++k) b += std::fabs(rows[i][k]) * dmax[k];
             ok = ok && (b < 5.7e17);  // 2^59; false for NaN/inf
+            if (i == 2) bz = b;
         }
+        // rounding error of cz is < 4 ulp of bz (2.4e-7 bz): the margin is 40x that, never below 1e-17
+        p.cz_margin = ok ? (float)std::fmax(1e-5 * bz, 1e-17) : 3.0e38f;
         ok = ok && std::fabs((double)p.fx) < 16384.0 && std::fabs((double)p.fy) < 16384.0 &&
              std::fabs((double)p.cx) < 1048576.0 && std::fabs((double)p.cy) < 1048576.0 &&
-             c.im_width < (1 << 20) && c.im_height < (1 << 20);
+             (int64_t)c.im_width * c.im_height <= (1 << 24);   // pixel index exact in fp32
         p.fast_ok = ok ? 1 : 0;
     }
     return p;
@@ -314,7 +318,7 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
         fp.ry0 = q.ry0; fp.ry1 = q.ry1; fp.ry2 = q.ry2;
         fp.rz0 = q.rz0; fp.rz1 = q.rz1; fp.rz2 = q.rz2;
         fp.tx = q.tx; fp.ty = q.ty; fp.tz = q.tz;
-        fp.fast_ok = q.fast_ok; fp.pad_ = 0;
+        fp.fast_ok = q.fast_ok; fp.cz_margin = q.cz_margin;
     }
     HIP_TRY(hipMemcpyAsync(v->d_frames[s], v->h_frames[s], n * sizeof(tsdfk::FramePose), hipMemcpyHostToDevice, v->stream));
     std::memcpy(v->last_cam2base, c2b + 16 * (n - 1), sizeof v->last_cam2base);

@@ -47,6 +47,9 @@ struct IntegrateParams {
     int nseg;               // ceil(dim_x / 256)
     // host-proved magnitude bounds that make the shared-reciprocal projection exact (see fast_div2)
     int fast_ok;
+    // |camera z| below which a lane's patch counts as "near the camera plane": far above the rounding
+    // error of cz over this slab (host: 1e-5 x the bound on |cz|), far above TSDF_FAST_D_MIN
+    float cz_margin;
 };
 
 // Terms of the camera-frame point that do not depend on x (shared by a lane's voxels).
@@ -335,18 +338,20 @@ __device__ __forceinline__ void integrate_tile_body(const IntegrateParams &p, co
     bool geo[R][4];
     int pixel[R][4];
     // camera-frame z of every voxel first: it decides which projection path the wavefront takes
-    bool unsafe = false;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const float dy = (p.oy + (float)(gy0 + r) * p.vs) - p.ty;   // ref: src/tsdf.cu:28,34
         const float z1 = p.rz1 * dy;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float cz = az[j] + z1 + z2;
-            pcz[r][j] = cz;
-            unsafe |= cz > 0.0f && cz < TSDF_FAST_D_MIN;
-        }
+        for (int j = 0; j < 4; ++j) pcz[r][j] = az[j] + z1 + z2;
     }
+    // The fast projection needs every cz of the wavefront outside (0, TSDF_FAST_D_MIN).  cz is affine
+    // over a lane's 4 x R patch, so its extremes sit at the patch corners (up to rounding, which the
+    // margin dwarfs): all corners > margin, or all < -margin (those voxels are rejected whatever the
+    // quotient), proves it with 6 instructions instead of two compares per voxel.
+    const float cmin = fminf(fminf(pcz[0][0], pcz[0][3]), fminf(pcz[R - 1][0], pcz[R - 1][3]));
+    const float cmax = fmaxf(fmaxf(pcz[0][0], pcz[0][3]), fmaxf(pcz[R - 1][0], pcz[R - 1][3]));
+    const bool unsafe = !(cmin > p.cz_margin) & !(cmax < -p.cz_margin);
     const bool fast = FAST && p.fast_ok != 0 && __ballot(unsafe) == 0ull;   // wave-uniform
     if (fast) {
         // Same values as the generic branch below, obtained with fewer instructions:
@@ -374,7 +379,8 @@ __device__ __forceinline__ void integrate_tile_body(const IntegrateParams &p, co
                 const bool ok = row_ok && cz > 0.0f && uv.x > -0.5f && uv.y > -0.5f && rd.x < (float)p.W &&
                                 rd.y < (float)p.H;
                 geo[r][j] = ok;
-                pixel[r][j] = ok ? (int)rd.y * p.W + (int)rd.x : 0;
+                // rd.y*W + rd.x < 2^24 (fast_ok): one exact fma + one conversion
+                pixel[r][j] = ok ? (int)__builtin_fmaf(rd.y, (float)p.W, rd.x) : 0;
             }
         }
     } else {

@@ -24,7 +24,7 @@ struct FramePose {
     const uint8_t *mask;     // may be null
     float rx0, rx1, rx2, ry0, ry1, ry2, rz0, rz1, rz2, tx, ty, tz;   // as IntegrateParams
     int fast_ok;
-    int pad_;
+    float cz_margin;
 };
 
 struct MultiParams {
@@ -85,17 +85,16 @@ __global__ __launch_bounds__(256) void integrate_multi(MultiParams mp)
         float pcz[R][4], dval[R][4];
         bool geo[R][4];
         int pixel[R][4];
-        bool unsafe = false;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const float z1 = q.rz1 * (byv[r] - q.ty);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float cz = az[j] + z1 + z2;
-                pcz[r][j] = cz;
-                unsafe |= cz > 0.0f && cz < TSDF_FAST_D_MIN;
-            }
+            for (int j = 0; j < 4; ++j) pcz[r][j] = az[j] + z1 + z2;
         }
+        // corner test of the patch against the camera plane, see integrate_tile
+        const float cmin = fminf(fminf(pcz[0][0], pcz[0][3]), fminf(pcz[R - 1][0], pcz[R - 1][3]));
+        const float cmax = fmaxf(fmaxf(pcz[0][0], pcz[0][3]), fmaxf(pcz[R - 1][0], pcz[R - 1][3]));
+        const bool unsafe = !(cmin > q.cz_margin) & !(cmax < -q.cz_margin);
         if (q.fast_ok != 0 && __ballot(unsafe) == 0ull) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -115,7 +114,8 @@ __global__ __launch_bounds__(256) void integrate_multi(MultiParams mp)
                     const bool ok = row_ok && cz > 0.0f && uv.x > -0.5f && uv.y > -0.5f && rd.x < (float)p.W &&
                                     rd.y < (float)p.H;
                     geo[r][j] = ok;
-                    pixel[r][j] = ok ? (int)rd.y * p.W + (int)rd.x : 0;
+                    // rd.y*W + rd.x < 2^24 (fast_ok): one exact fma + one conversion
+                pixel[r][j] = ok ? (int)__builtin_fmaf(rd.y, (float)p.W, rd.x) : 0;
                 }
             }
         } else {
