@@ -190,6 +190,19 @@ int tsdf_extract_surface(tsdf_volume *vol, float weight_thresh, float *xyz_host,
                          int64_t *count);
 
 /*
+ * Zero-crossing surface vertices (the vertex set of marching cubes), compacted on the device in
+ * grid order: for every voxel and every +x, +y, +z neighbour with both weights > weight_thresh and
+ * TSDF values of opposite sign, the linearly interpolated crossing point.  Not a reference
+ * function (its mesh path is the absent tsdf-fusion-python, ref: src/TSDFfusion.py.in:48-53); the
+ * rule is defined in oracle/tsdf_oracle.c (oracle_zero_crossings) and csrc/tsdf_extract.hip.h.
+ * halo_tsdf / halo_weight: the dim_y*dim_x values of global slice z_end -- what a z-slab owner
+ * receives from its upper neighbour (host or device memory) -- or both NULL on the top slab.
+ * Call with xyz_host == NULL to get *count only.  Synchronous.
+ */
+int tsdf_extract_crossings(tsdf_volume *vol, const float *halo_tsdf, const float *halo_weight, float weight_thresh,
+                           float *xyz_host, int64_t capacity, int64_t *count);
+
+/*
  * File writers, byte-compatible with the reference's destructor (ref: src/tsdf.cu:107-132,
  * 170-218).  For a slab handle the .bin header carries the slab's dims and a z-shifted
  * origin is NOT applied: callers that shard gather slabs in z order first (see

@@ -203,6 +203,56 @@ int64_t oracle_surface_points(const float *tsdf, const float *weight,
     return n;
 }
 
+/* ------------------------------------------------------------------------------------
+ * Zero-crossing surface vertices (NOT in the reference: its only extractor is the per-voxel
+ * rule above; its mesh path lives in the absent tsdf-fusion-python, ref: src/TSDFfusion.py.in:48-53).
+ * Definition used by this project, restated here for the HIP kernel to be checked against --
+ * parity unpinned by any reference output:
+ *   for every voxel v in grid order and every axis a in x, y, z order, with n = v + e_a inside the
+ *   grid (for a = z the slice above the slab comes from `halo_*`, or the edge is skipped when they
+ *   are NULL): if weight(v) > thresh and weight(n) > thresh and (tsdf(v) < 0) != (tsdf(n) < 0),
+ *   emit  p(v) + s * voxel_size * e_a  with  s = tsdf(v) / (tsdf(v) - tsdf(n))  (fp32, one division),
+ *   p(v) = origin + index * voxel_size as in tsdf.cu:206-208, and the a-coordinate computed as
+ *   p_a(v) + s * voxel_size (one multiply, one add).
+ * tsdf/weight hold slices [z_begin, z_end); halo_* hold slice z_end (dim_x*dim_y floats).
+ * ---------------------------------------------------------------------------------- */
+int64_t oracle_zero_crossings(const float *tsdf, const float *weight, const float *halo_tsdf,
+                              const float *halo_weight, int dim_x, int dim_y, int z_begin, int z_end,
+                              float voxel_size, float origin_x, float origin_y, float origin_z,
+                              float weight_thresh, float *xyz)
+{
+    int64_t n = 0;
+    const int64_t slice = (int64_t)dim_x * dim_y;
+    for (int z = z_begin; z < z_end; ++z)
+        for (int y = 0; y < dim_y; ++y)
+            for (int x = 0; x < dim_x; ++x) {
+                const int64_t i = (int64_t)(z - z_begin) * slice + (int64_t)y * dim_x + x;
+                const float t0 = tsdf[i];
+                if (!(weight[i] > weight_thresh)) continue;
+                const float px = origin_x + (float)x * voxel_size;
+                const float py = origin_y + (float)y * voxel_size;
+                const float pz = origin_z + (float)z * voxel_size;
+                for (int a = 0; a < 3; ++a) {
+                    float t1, w1;
+                    if (a == 0) { if (x + 1 >= dim_x) continue; t1 = tsdf[i + 1]; w1 = weight[i + 1]; }
+                    else if (a == 1) { if (y + 1 >= dim_y) continue; t1 = tsdf[i + dim_x]; w1 = weight[i + dim_x]; }
+                    else if (z + 1 < z_end) { t1 = tsdf[i + slice]; w1 = weight[i + slice]; }
+                    else { if (!halo_tsdf || !halo_weight) continue; t1 = halo_tsdf[(int64_t)y * dim_x + x]; w1 = halo_weight[(int64_t)y * dim_x + x]; }
+                    if (!(w1 > weight_thresh)) continue;
+                    if ((t0 < 0.0f) == (t1 < 0.0f)) continue;
+                    if (xyz) {
+                        const float s = t0 / (t0 - t1);
+                        const float d = s * voxel_size;
+                        xyz[3 * n + 0] = a == 0 ? px + d : px;
+                        xyz[3 * n + 1] = a == 1 ? py + d : py;
+                        xyz[3 * n + 2] = a == 2 ? pz + d : pz;
+                    }
+                    ++n;
+                }
+            }
+    return n;
+}
+
 /* .ply writer: header text of tsdf.cu:185-192, then 3 floats per point (tsdf.cu:210-212). */
 int oracle_save_ply(const char *path, const float *tsdf, const float *weight,
                     int dim_x, int dim_y, int dim_z, float voxel_size,

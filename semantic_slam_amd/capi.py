@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "tsdf_integrate_frames_device",
     "tsdf_sync", "tsdf_download", "tsdf_copy_slices", "tsdf_upload", "tsdf_refresh_summary", "tsdf_device_ptrs", "tsdf_slab_voxels",
     "tsdf_get_config", "tsdf_last_cam2base", "tsdf_set_stream", "tsdf_get_stream",
-    "tsdf_count_surface", "tsdf_extract_surface", "tsdf_save_ply", "tsdf_save_bin",
+    "tsdf_count_surface", "tsdf_extract_surface", "tsdf_extract_crossings", "tsdf_save_ply", "tsdf_save_bin",
     "tsdf_integrate_sequence_timed", "tsdf_probe_stream", "tsdf_selftest_fastdiv", "tsdf_set_kernel_variant", "tsdf_last_error",
     "tsdf_version", "tsdf_multiply_matrix", "tsdf_invert_matrix",
     "tsdf_batch_create", "tsdf_batch_destroy", "tsdf_batch_size", "tsdf_batch_volume",
@@ -83,6 +83,7 @@ def load():
     L.tsdf_get_stream.argtypes = [vp, C.POINTER(vp)]
     L.tsdf_count_surface.argtypes = [vp, C.c_float, i64p]
     L.tsdf_extract_surface.argtypes = [vp, C.c_float, vp, C.c_int64, i64p]
+    L.tsdf_extract_crossings.argtypes = [vp, vp, vp, C.c_float, vp, C.c_int64, i64p]
     L.tsdf_save_ply.argtypes = [vp, C.c_char_p, C.c_float]
     L.tsdf_save_bin.argtypes = [vp, C.c_char_p]
     L.tsdf_integrate_sequence_timed.argtypes = [vp, vp, vp, C.c_int32, f32p]
@@ -324,6 +325,27 @@ class Volume:
         check(self.lib.tsdf_extract_surface(self._h, weight_thresh, xyz.ctypes.data, n, C.byref(got)),
               "tsdf_extract_surface")
         assert got.value == n
+        return xyz
+
+    def extract_crossings(self, halo=None, weight_thresh=0.9):
+        """Zero-crossing vertices of the slab; halo = (tsdf, weight) of slice z_end as numpy arrays,
+        or a pair of device pointers (ints), or None on the top slab."""
+        ht = hw = None
+        keep = None
+        if halo is not None:
+            if isinstance(halo[0], (int, np.integer)):
+                ht, hw = int(halo[0]), int(halo[1])
+            else:
+                keep = (_f32(halo[0]), _f32(halo[1]))
+                ht, hw = keep[0].ctypes.data, keep[1].ctypes.data
+        n = C.c_int64()
+        check(self.lib.tsdf_extract_crossings(self._h, ht, hw, weight_thresh, None, 0, C.byref(n)), "tsdf_extract_crossings")
+        xyz = np.empty((n.value, 3), np.float32)
+        if n.value:
+            got = C.c_int64()
+            check(self.lib.tsdf_extract_crossings(self._h, ht, hw, weight_thresh, xyz.ctypes.data, n.value, C.byref(got)),
+                  "tsdf_extract_crossings")
+            assert got.value == n.value
         return xyz
 
     def save_ply(self, path, weight_thresh=0.9):

@@ -984,6 +984,69 @@ int tsdf_extract_surface(tsdf_volume *v, float weight_thresh, float *xyz_host, i
     return surface_pass(v, weight_thresh, xyz_host, capacity, count);
 }
 
+// Zero-crossing vertices.  halo_*: slice z_end from the upper neighbour (host or device memory) or NULL.
+static int crossing_pass(tsdf_volume *v, const float *halo_tsdf, const float *halo_weight, float weight_thresh,
+                         float *xyz_host, int64_t capacity, int64_t *count)
+{
+    int rc = bind_device(v);
+    if (rc) return rc;
+    *count = 0;
+    if (v->n_vox == 0) return TSDF_OK;
+    if ((halo_tsdf == nullptr) != (halo_weight == nullptr))
+        return fail(TSDF_ERR_INVALID, "zero crossings: give both halo arrays or neither");
+    const tsdf_config &c = v->cfg;
+    const int64_t n = v->n_vox;
+    const int64_t n_chunks = (n + tsdfx::kChunk - 1) / tsdfx::kChunk;
+    if (n_chunks > 0x7fffffff) return fail(TSDF_ERR_INVALID, "zero crossings: slab too large");
+    const size_t slice = (size_t)c.dim_x * c.dim_y;
+    // scratch: counts (u32) | offsets (i64) | total (i64) | halo copy (2 slices of floats)
+    size_t off_offsets = ((size_t)n_chunks * sizeof(uint32_t) + 255) & ~(size_t)255;
+    size_t off_total = off_offsets + (size_t)n_chunks * sizeof(int64_t);
+    size_t off_halo = (off_total + 256 + 255) & ~(size_t)255;
+    rc = ensure_scratch(v, off_halo + 2 * slice * sizeof(float));
+    if (rc) return rc;
+    char *s = (char *)v->d_scratch;
+    uint32_t *d_counts = (uint32_t *)s;
+    int64_t *d_offsets = (int64_t *)(s + off_offsets);
+    int64_t *d_total = (int64_t *)(s + off_total);
+    float *d_halo = (float *)(s + off_halo);
+    tsdfx::CrossingGrid g;
+    g.tsdf = v->d_tsdf; g.weight = v->d_weight; g.halo_tsdf = nullptr; g.halo_weight = nullptr;
+    if (halo_tsdf) {   // host or device source: stage both slices in our scratch
+        HIP_TRY(hipMemcpyAsync(d_halo, halo_tsdf, slice * sizeof(float), hipMemcpyDefault, v->stream));
+        HIP_TRY(hipMemcpyAsync(d_halo + slice, halo_weight, slice * sizeof(float), hipMemcpyDefault, v->stream));
+        g.halo_tsdf = d_halo; g.halo_weight = d_halo + slice;
+    }
+    g.n = n; g.dim_x = c.dim_x; g.dim_y = c.dim_y; g.nz = c.z_end - c.z_begin; g.z_begin = c.z_begin;
+    g.thr = weight_thresh; g.ox = c.origin[0]; g.oy = c.origin[1]; g.oz = c.origin[2]; g.vs = c.voxel_size;
+    hipLaunchKernelGGL(tsdfx::crossing_count, dim3((unsigned)n_chunks), dim3(256), 0, v->stream, g, d_counts);
+    hipLaunchKernelGGL(tsdfx::scan_counts, dim3(1), dim3(1024), 0, v->stream, d_counts, n_chunks, d_offsets, d_total);
+    HIP_TRY(hipGetLastError());
+    int64_t total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, d_total, sizeof total, hipMemcpyDeviceToHost, v->stream));
+    HIP_TRY(hipStreamSynchronize(v->stream));
+    *count = total;
+    if (!xyz_host || capacity <= 0 || total == 0) return TSDF_OK;
+    const int64_t n_out = total < capacity ? total : capacity;
+    float *d_xyz = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_xyz, (size_t)total * 3 * sizeof(float)));
+    hipLaunchKernelGGL(tsdfx::crossing_emit, dim3((unsigned)n_chunks), dim3(256), 0, v->stream, g, d_offsets, d_xyz);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(xyz_host, d_xyz, (size_t)n_out * 3 * sizeof(float), hipMemcpyDeviceToHost, v->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(v->stream);
+    (void)hipFree(d_xyz);
+    if (e != hipSuccess) return fail(TSDF_ERR_HIP, "zero crossings: %s", hipGetErrorString(e));
+    return TSDF_OK;
+}
+
+int tsdf_extract_crossings(tsdf_volume *v, const float *halo_tsdf, const float *halo_weight, float weight_thresh,
+                           float *xyz_host, int64_t capacity, int64_t *count)
+{
+    if (!v || !count) return fail(TSDF_ERR_INVALID, "tsdf_extract_crossings: NULL argument");
+    return crossing_pass(v, halo_tsdf, halo_weight, weight_thresh, xyz_host, capacity, count);
+}
+
 int tsdf_save_ply(tsdf_volume *v, const char *path, float weight_thresh)
 {
     if (!v || !path) return fail(TSDF_ERR_INVALID, "tsdf_save_ply: NULL argument");

@@ -112,4 +112,113 @@ __global__ __launch_bounds__(256) void surface_emit(const float *tsdf, const flo
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Zero-crossing surface vertices (the vertex set of marching cubes): for voxel v and axis a with
+// neighbour n = v + e_a, both weights > thr and tsdf(v), tsdf(n) of opposite sign -> the point
+// p(v) + (tsdf(v) / (tsdf(v) - tsdf(n))) * voxel_size * e_a.  Not in the reference (its mesh path
+// is the absent Python package); the rule is this project's own and is checked bit for bit against
+// its CPU restatement in the test suite (tests/test_gpu_crossings.py).  The +z neighbours of a slab's top
+// slice come from `halo_*` -- the one-voxel halo a z-slab rank receives from its upper
+// neighbour (RCCL send/recv, semantic_slam_amd/sharded.py) -- or are skipped when it is null.
+// Same three-pass order-preserving compaction as the point extractor; a voxel emits up to three
+// points, in x, y, z edge order.
+// ------------------------------------------------------------------------------------------
+struct CrossingGrid {
+    const float *tsdf, *weight, *halo_tsdf, *halo_weight;
+    int64_t n;          // voxels in the slab
+    int dim_x, dim_y, nz, z_begin;
+    float thr, ox, oy, oz, vs;
+};
+
+// bit a set = the edge from voxel i along axis a crosses zero
+__device__ __forceinline__ uint32_t crossing_bits(const CrossingGrid &g, int64_t i, float &t0, float t1[3])
+{
+    if (i >= g.n) return 0u;
+    t0 = g.tsdf[i];
+    if (!(g.weight[i] > g.thr)) return 0u;
+    const int64_t slice = (int64_t)g.dim_x * g.dim_y;
+    const int lz = (int)(i / slice);
+    const int rem = (int)(i - (int64_t)lz * slice);
+    const int y = rem / g.dim_x, x = rem - y * g.dim_x;
+    uint32_t bits = 0u;
+    if (x + 1 < g.dim_x) {
+        t1[0] = g.tsdf[i + 1];
+        if (g.weight[i + 1] > g.thr && ((t0 < 0.0f) != (t1[0] < 0.0f))) bits |= 1u;
+    }
+    if (y + 1 < g.dim_y) {
+        t1[1] = g.tsdf[i + g.dim_x];
+        if (g.weight[i + g.dim_x] > g.thr && ((t0 < 0.0f) != (t1[1] < 0.0f))) bits |= 2u;
+    }
+    if (lz + 1 < g.nz) {
+        t1[2] = g.tsdf[i + slice];
+        if (g.weight[i + slice] > g.thr && ((t0 < 0.0f) != (t1[2] < 0.0f))) bits |= 4u;
+    } else if (g.halo_tsdf != nullptr) {
+        t1[2] = g.halo_tsdf[rem];
+        if (g.halo_weight[rem] > g.thr && ((t0 < 0.0f) != (t1[2] < 0.0f))) bits |= 4u;
+    }
+    return bits;
+}
+
+__global__ __launch_bounds__(256) void crossing_count(CrossingGrid g, uint32_t *counts)
+{
+    __shared__ uint32_t wave_sum[4];
+    const int64_t base = (int64_t)blockIdx.x * kChunk;
+    uint32_t c = 0;
+    for (int k = 0; k < kPerThread; ++k) {
+        float t0, t1[3];
+        c += (uint32_t)__popc(crossing_bits(g, base + k * 256 + threadIdx.x, t0, t1));
+    }
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+    if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+}
+
+__global__ __launch_bounds__(256) void crossing_emit(CrossingGrid g, const int64_t *offsets, float *xyz)
+{
+    __shared__ uint32_t cnt[kPerThread * 4];  // [k][wave] in output order
+    const int64_t base = (int64_t)blockIdx.x * kChunk;
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    for (int k = 0; k < kPerThread; ++k) {
+        float t0, t1[3];
+        uint32_t c = (uint32_t)__popc(crossing_bits(g, base + k * 256 + threadIdx.x, t0, t1));
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+        if (lane == 0) cnt[k * 4 + wave] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int j = 0; j < kPerThread * 4; ++j) { uint32_t c = cnt[j]; cnt[j] = run; run += c; }
+    }
+    __syncthreads();
+    const int64_t chunk_off = offsets[blockIdx.x];
+    const int64_t slice = (int64_t)g.dim_x * g.dim_y;
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    for (int k = 0; k < kPerThread; ++k) {
+        const int64_t i = base + k * 256 + threadIdx.x;
+        float t0, t1[3];
+        const uint32_t bits = crossing_bits(g, i, t0, t1);
+        // points emitted by lower lanes of this wavefront for this k (all three axes), then own axes in order
+        const unsigned long long bx = __ballot(bits & 1u), by = __ballot(bits & 2u), bz = __ballot(bits & 4u);
+        if (bits == 0u) continue;
+        int64_t pos = chunk_off + cnt[k * 4 + wave] + __popcll(bx & lt) + __popcll(by & lt) + __popcll(bz & lt);
+        const int lz = (int)(i / slice);
+        const int rem = (int)(i - (int64_t)lz * slice);
+        const int y = rem / g.dim_x, x = rem - y * g.dim_x;
+        const float px = g.ox + (float)x * g.vs;
+        const float py = g.oy + (float)y * g.vs;
+        const float pz = g.oz + (float)(g.z_begin + lz) * g.vs;
+        for (int a = 0; a < 3; ++a) {
+            if (!(bits & (1u << a))) continue;
+            const float s = t0 / (t0 - t1[a]);
+            const float d = s * g.vs;
+            xyz[3 * pos + 0] = a == 0 ? px + d : px;
+            xyz[3 * pos + 1] = a == 1 ? py + d : py;
+            xyz[3 * pos + 2] = a == 2 ? pz + d : pz;
+            ++pos;
+        }
+    }
+}
+
 }  // namespace tsdfx

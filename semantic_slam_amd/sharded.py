@@ -138,6 +138,21 @@ class ShardedVolume:
             dist.send(buf, self._global_rank(dst), group=self.group)
         return None, None
 
+    def gather_crossings(self, weight_thresh=0.9, dst=0):
+        """Zero-crossing vertices of the whole grid in grid order on rank dst.  This is the
+        neighbourhood-based extraction the halo exists for: every rank first receives slice z_end
+        from its upper neighbour (halo_exchange, RCCL/gloo), extracts its slab's vertices on its
+        device, and the lists are concatenated in z order -- identical to the unsharded list."""
+        ht, hw = self.halo_exchange()
+        pts = self.slab.extract_crossings(None if ht is None else (ht, hw), weight_thresh)
+        if self.world == 1:
+            return pts
+        gathered = [None] * self.world if self.rank == dst else None
+        self.dist.gather_object(pts, gathered, dst=self._global_rank(dst), group=self.group)
+        if self.rank != dst:
+            return None
+        return np.concatenate([g.reshape(-1, 3) for g in gathered]).astype(np.float32)
+
     def gather_surface(self, weight_thresh=0.9, dst=0):
         """Surface points of the whole grid in grid order on rank dst (ref rule: src/tsdf.cu:179).
         Per-voxel rule: each rank compacts its own slab on its GPU, lists are concatenated in z order."""

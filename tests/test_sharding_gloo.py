@@ -43,6 +43,9 @@ class OracleSlab:
         s = DIMS[0] * DIMS[1]
         return self.t[z_local * s:(z_local + n) * s].copy(), self.w[z_local * s:(z_local + n) * s].copy()
 
+    def extract_crossings(self, halo=None, thr=0.9):
+        return self.o.zero_crossings(self.t, self.w, DIMS[:2], self.zb, self.ze, VS, self.origin, halo, thr)
+
     def extract_surface(self, thr=0.9):
         dims = (DIMS[0], DIMS[1], self.ze - self.zb)
         pts = self.o.surface_points(self.t, self.w, dims, VS, self.origin, thr)
@@ -70,7 +73,8 @@ def worker(rank, world, port, q):
         ht, hw = vol.halo_exchange()
         t, w = vol.gather(dst=0)
         pts = vol.gather_surface(dst=0)
-        q.put((rank, ht, hw, t, w, pts))
+        xing = vol.gather_crossings(dst=0)
+        q.put((rank, ht, hw, t, w, pts, xing))
     finally:
         dist.destroy_process_group()
 
@@ -102,10 +106,12 @@ def test_sharded_equals_whole(world):
     whole = OracleSlab(0, DIMS[2])
     for pose, depth in frames():
         whole.integrate(depth, pose)
-    _, _, t, w, pts = out[0]
+    _, _, t, w, pts, xing = out[0]
     assert whole.w.sum() > 0
     assert np.array_equal(w, whole.w) and np.array_equal(t.view(np.uint32), whole.t.view(np.uint32))
     assert np.array_equal(pts.view(np.uint32), whole.extract_surface().view(np.uint32))
+    want_x = whole.extract_crossings(None)
+    assert len(want_x) > 100 and np.array_equal(xing.view(np.uint32), want_x.view(np.uint32))
     s = DIMS[0] * DIMS[1]
     for r in range(world):
         zb, ze = slab_range(DIMS[2], r, world)
