@@ -41,7 +41,9 @@ def test_no_oracle_in_product():
             assert "oracle" not in open(os.path.join(ROOT, "semantic_slam_amd", fn)).read().replace(
                 "oracle/", ""), fn  # mentions of the directory in docstrings are fine, imports are not
     for fn in os.listdir(os.path.join(ROOT, "semantic_slam_amd", "csrc")):
-        assert "oracle" not in open(os.path.join(ROOT, "semantic_slam_amd", "csrc", fn)).read(), fn
+        path = os.path.join(ROOT, "semantic_slam_amd", "csrc", fn)
+        if os.path.isfile(path):
+            assert "oracle" not in open(path).read(), fn
 
 
 def test_struct_layout_matches_c(tmp_path):
