@@ -174,6 +174,7 @@ tsdfk::IntegrateParams make_params(const tsdf_volume *v, const float *depth_dev,
 //   64 + c   early loads without the summary
 //   80 + c   summary + exact shared-reciprocal projection (fast_div2)
 //   96 + c   shared-reciprocal projection without the summary
+//   112 + c  as 80 + c with the depth pixels of each workgroup's patch staged in LDS (c = 3, 7: R = 1, 2)
 constexpr int kDefaultTile = 80 + ((1 << 2) | (1 << 1) | 1);  // R = 2, elide, nt, summary, fast projection
 
 template <int R, bool ELIDE, bool NT, bool MASKED, bool SUM, bool EARLY = false, bool FAST = false>
@@ -226,7 +227,8 @@ int launch_integrate(tsdf_volume *v, const float *depth_dev, const uint8_t *mask
     // which launches keep the free-space summary up to date: the SUM kernels (variants >= 32 and the
     // masked form of the tile kernel); the rows kernels and the plain tile variants do not
     const bool summary = variant != 1 && variant != 2 &&
-                         (mask_dev != nullptr || (variant >= 32 && variant < 64) || (variant >= 80 && variant < 96));
+                         (mask_dev != nullptr || (variant >= 32 && variant < 64) || (variant >= 80 && variant < 96) ||
+                          variant >= 112);
     if (!summary) {
         int rc = drop_summary(v);
         if (rc) return rc;
@@ -256,6 +258,10 @@ int launch_integrate(tsdf_volume *v, const float *depth_dev, const uint8_t *mask
             FAST_CASE(64 + 6, 2, false, false) FAST_CASE(64 + 7, 2, true, false)
             FAST_CASE(64 + 10, 4, false, false) FAST_CASE(64 + 11, 4, true, false)
 #undef FAST_CASE
+            case 80 + 3: hipLaunchKernelGGL((tsdfk::integrate_tile<1, true, true, false, true, false, true, true>),
+                                            dim3((p.xgroups + 63) / 64, (p.dim_y + 3) / 4, p.nz), dim3(64, 4, 1), 0, v->stream, p); break;
+            case 80 + 7: hipLaunchKernelGGL((tsdfk::integrate_tile<2, true, true, false, true, false, true, true>),
+                                            dim3((p.xgroups + 63) / 64, (p.dim_y + 7) / 8, p.nz), dim3(64, 4, 1), 0, v->stream, p); break;
             SUM_CASE(2, 1, false, true, false) SUM_CASE(3, 1, true, true, false)
             SUM_CASE(6, 2, false, true, false) SUM_CASE(7, 2, true, true, false)
             SUM_CASE(10, 4, false, true, false) SUM_CASE(11, 4, true, true, false)
@@ -718,7 +724,7 @@ int tsdf_set_kernel_variant(tsdf_volume *v, int32_t variant)
 {
     if (!v) return fail(TSDF_ERR_INVALID, "tsdf_set_kernel_variant: NULL handle");
     const int c = (variant - 32) & 15;
-    const bool sum_ok = variant >= 32 && variant < 112 && c < 12 && ((c >> 1) & 1);
+    const bool sum_ok = (variant >= 32 && variant < 112 && c < 12 && ((c >> 1) & 1)) || variant == 115 || variant == 119;
     if (!(variant >= 0 && variant <= 4) && !(variant >= 16 && variant < 28) && !sum_ok)
         return fail(TSDF_ERR_INVALID, "tsdf_set_kernel_variant: unknown variant %d", variant);
     v->variant = variant;

@@ -277,13 +277,58 @@ __device__ __forceinline__ bool patch_may_be_visible(const IntegrateParams &p, i
 
 // MASKED: 0 = plain depth, 1 = depth * (mask/255) (p.mask must be set), 2 = decided per launch
 // parameter block (p.mask may be null) -- the batched kernel, where each object brings its own.
-template <int R, bool ELIDE, bool NT, int MASKED, bool SUM, bool EARLY, bool FAST>
+// LDSD: stage the depth pixels the workgroup's voxel patch projects onto in LDS and sample from there
+// (the north-star sketch).  Kept as a measured experiment: the frame lives in every XCD's L2 and the
+// kernel is VALU-issue-bound, so the extra bounding-box / index arithmetic costs more than the L1/L2
+// gathers it replaces.
+constexpr int kLdsTile = 4096;   // floats: 16 KiB per workgroup, 8+ workgroups per CU still fit
+
+template <int R, bool ELIDE, bool NT, int MASKED, bool SUM, bool EARLY, bool FAST, bool LDSD = false>
 __device__ __forceinline__ void integrate_tile_body(const IntegrateParams &p, const int bx, const int by, const int lz)
 {
+    const int gz = p.z_begin + lz;
+    // ---- (LDSD) depth tile of the workgroup's 256 x 4R voxel patch -------------------------------
+    __shared__ float lds_depth[LDSD ? kLdsTile : 1];
+    int tu0 = 0, tv0 = 0, tw = 0, th = 0;   // tile origin and size in pixels (workgroup-uniform); tw = 0: no tile
+    if constexpr (LDSD) {
+        const int lane = threadIdx.x & 63;
+        const int x0 = bx * 256, x1 = min(x0 + 255, p.dim_x - 1);
+        const int y0 = by * 4 * R, y1 = min(y0 + 4 * R - 1, p.dim_y - 1);
+        // lanes 0..3 project the four corners (approximate arithmetic: the tile only has to CONTAIN the
+        // exact pixels; a voxel whose exact pixel falls outside it reads global memory instead)
+        const float qx = p.ox + (float)((lane & 1) ? x1 : x0) * p.vs - p.tx;
+        const float qy = p.oy + (float)((lane & 2) ? y1 : y0) * p.vs - p.ty;
+        const float qz = p.oz + (float)gz * p.vs - p.tz;
+        const float ccx = p.rx0 * qx + p.rx1 * qy + p.rx2 * qz;
+        const float ccy = p.ry0 * qx + p.ry1 * qy + p.ry2 * qz;
+        const float ccz = p.rz0 * qx + p.rz1 * qy + p.rz2 * qz;
+        const float inv = __builtin_amdgcn_rcpf(ccz);
+        float u = p.fx * (ccx * inv) + p.cx, v = p.fy * (ccy * inv) + p.cy;
+        float umin = u, umax = u, vmin = v, vmax = v, zmin = ccz;
+#pragma unroll
+        for (int m = 1; m <= 2; m <<= 1) {
+            umin = fminf(umin, __shfl_xor(umin, m)); umax = fmaxf(umax, __shfl_xor(umax, m));
+            vmin = fminf(vmin, __shfl_xor(vmin, m)); vmax = fmaxf(vmax, __shfl_xor(vmax, m));
+            zmin = fminf(zmin, __shfl_xor(zmin, m));
+        }
+        umin = __shfl(umin, 0); umax = __shfl(umax, 0); vmin = __shfl(vmin, 0); vmax = __shfl(vmax, 0);
+        zmin = __shfl(zmin, 0);
+        // all corners in front of the camera and a sane box -> clip to the image, 2-pixel safety border
+        if (zmin > 0.0f && umax - umin < 4096.0f && vmax - vmin < 4096.0f && umin > -1.0e6f && vmin > -1.0e6f &&
+            umax < 1.0e6f && vmax < 1.0e6f) {
+            const int a0 = max(0, (int)floorf(umin) - 2), a1 = min(p.W - 1, (int)ceilf(umax) + 2);
+            const int b0 = max(0, (int)floorf(vmin) - 2), b1 = min(p.H - 1, (int)ceilf(vmax) + 2);
+            const int w_ = a1 - a0 + 1, h_ = b1 - b0 + 1;
+            if (w_ > 0 && h_ > 0 && w_ * h_ <= kLdsTile) { tu0 = a0; tv0 = b0; tw = w_; th = h_; }
+        }
+        for (int ty = threadIdx.y; ty < th; ty += 4)
+            for (int tx = lane; tx < tw; tx += 64)
+                lds_depth[ty * tw + tx] = p.depth[(size_t)(tv0 + ty) * p.W + (tu0 + tx)];
+        __syncthreads();
+    }
     const int xg = bx * 64 + threadIdx.x;
     const int gy0 = (by * 4 + threadIdx.y) * R;
     if (xg >= p.xgroups || gy0 >= p.dim_y) return;
-    const int gz = p.z_begin + lz;
     const size_t row0 = ((size_t)lz * p.dim_y + gy0) * (size_t)p.dim_x + (size_t)xg * 4;
     const size_t flag0 = ((size_t)lz * p.dim_y + gy0) * (size_t)p.nseg + bx;
 
@@ -337,6 +382,7 @@ __device__ __forceinline__ void integrate_tile_body(const IntegrateParams &p, co
     float pcz[R][4], dval[R][4];
     bool geo[R][4];
     int pixel[R][4];
+    int pix_u[LDSD ? R : 1][4], pix_v[LDSD ? R : 1][4];   // (LDSD) the pixel as column / row
     // camera-frame z of every voxel first: it decides which projection path the wavefront takes
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -381,6 +427,7 @@ __device__ __forceinline__ void integrate_tile_body(const IntegrateParams &p, co
                 geo[r][j] = ok;
                 // rd.y*W + rd.x < 2^24 (fast_ok): one exact fma + one conversion
                 pixel[r][j] = ok ? (int)__builtin_fmaf(rd.y, (float)p.W, rd.x) : 0;
+                if constexpr (LDSD) { pix_u[r][j] = ok ? (int)rd.x : 0; pix_v[r][j] = ok ? (int)rd.y : 0; }
             }
         }
     } else {
@@ -404,6 +451,7 @@ __device__ __forceinline__ void integrate_tile_body(const IntegrateParams &p, co
                                 pv < (float)p.H;
                 geo[r][j] = ok;
                 pixel[r][j] = ok ? (int)pv * p.W + (int)pu : 0;
+                if constexpr (LDSD) { pix_u[r][j] = ok ? (int)pu : 0; pix_v[r][j] = ok ? (int)pv : 0; }
             }
         }
     }
@@ -413,7 +461,14 @@ __device__ __forceinline__ void integrate_tile_body(const IntegrateParams &p, co
         for (int j = 0; j < 4; ++j) {
             // unsigned 32-bit offset from a wave-uniform base: the load takes the base from SGPRs
             const uint32_t px = (uint32_t)pixel[r][j];
-            float d = p.depth[px];
+            float d;
+            if constexpr (LDSD) {
+                const uint32_t du = (uint32_t)(pix_u[r][j] - tu0), dv = (uint32_t)(pix_v[r][j] - tv0);
+                if (du < (uint32_t)tw && dv < (uint32_t)th) d = lds_depth[dv * tw + du];
+                else d = p.depth[px];   // outside the staged tile (or no tile): the exact pixel from memory
+            } else {
+                d = p.depth[px];
+            }
             if (MASKED == 1 || (MASKED == 2 && p.mask != nullptr))
                 d = d * (p.mask[px] >= 128 ? 1.0f : 0.0f);  // ref: src/Engine.cpp:192-193
             dval[r][j] = d;
@@ -520,10 +575,11 @@ __device__ __forceinline__ void integrate_tile_body(const IntegrateParams &p, co
     }
 }
 
-template <int R, bool ELIDE, bool NT, bool MASKED, bool SUM = false, bool EARLY = false, bool FAST = false>
+template <int R, bool ELIDE, bool NT, bool MASKED, bool SUM = false, bool EARLY = false, bool FAST = false,
+          bool LDSD = false>
 __global__ __launch_bounds__(256) void integrate_tile(IntegrateParams p)
 {
-    integrate_tile_body<R, ELIDE, NT, MASKED ? 1 : 0, SUM, EARLY, FAST>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+    integrate_tile_body<R, ELIDE, NT, MASKED ? 1 : 0, SUM, EARLY, FAST, LDSD>(p, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Many volumes, one frame, one launch (the reference's real usage: one small TSDF per object

@@ -72,7 +72,7 @@ def test_integrate_matches_oracle(cuda, oracle, dims, vs, z0, rand_base, frames)
 
 # free-space summary (32+), summary + early loads (48+), early loads only (64+)
 # ... and the exact shared-reciprocal projection with (80+) / without (96+) the summary
-SUM_VARIANTS = [b + c for b in (32, 48, 64, 80, 96) for c in (2, 3, 6, 7, 10, 11)]
+SUM_VARIANTS = [b + c for b in (32, 48, 64, 80, 96) for c in (2, 3, 6, 7, 10, 11)] + [115, 119]   # 11x: depth tile in LDS
 
 
 @pytest.mark.parametrize("variant", [0, 1, 2] + list(range(16, 28)) + SUM_VARIANTS)

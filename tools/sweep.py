@@ -45,5 +45,5 @@ print(f"workload {workload} D={D}: updated fraction {upd / N:.3f}")
 for v in variants:
     ms = min(res[v]); med = sorted(res[v])[1]
     c = (v - 16) & 15
-    desc = "rows<4> v0" if v == 2 else f"tile R={[1, 2, 4][c >> 2]} elide={(c >> 1) & 1} nt={c & 1} sum={int(32 <= v < 64 or 80 <= v < 96)} early={int(48 <= v < 80)} fast={int(v >= 80)}"
+    desc = "rows<4> v0" if v == 2 else f"tile R={[1, 2, 4][c >> 2]} elide={(c >> 1) & 1} nt={c & 1} sum={int(32 <= v < 64 or 80 <= v < 96)} early={int(48 <= v < 80)} fast={int(v >= 80)} lds={int(v >= 112)}"
     print(f"variant {v:2d} {desc:28s} min {ms:.4f} med {med:.4f} ms  {N / ms / 1e3:9.0f} Mvox/s  alg {(16 * upd + 1.2e6) / ms / 1e6:7.0f} GB/s")
