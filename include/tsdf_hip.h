@@ -238,6 +238,27 @@ int tsdf_selftest_fastdiv(int32_t device, uint64_t seed, uint64_t n_samples, uin
 int tsdf_set_kernel_variant(tsdf_volume *vol, int32_t variant);
 
 /*
+ * Per-voxel semantic-label fusion (BASELINE config 5).  Not a function of the reference's TSDF:
+ * the reference fuses instance evidence per sparse ObjectPoint -- Fp += score inside a mask of the
+ * point's object, Bp += score otherwise, P = Fp/(Fp+Bp), dropped below a threshold
+ * (ref: src/ObjectPoint.cpp:190-219,149-154; Engine.mProbThd = 0.5, config/TUM3.yaml:92); the same
+ * rule is applied here per voxel of the dense grid (csrc/tsdf_labels.hip.h states it exactly).
+ *   tsdf_labels_enable        allocate (or clear) label:uint16, Fp:f32, Bp:f32 arrays for the slab
+ *   tsdf_compose_labels       K instance masks (MaskRCNN format, ref: src/MaskRCNN.cpp:316-362:
+ *                             K*H*W uint8 {0,255} in device memory, label and score per instance on
+ *                             the host) -> one label image + one score image on the device
+ *   tsdf_integrate_labels_device  one frame: voxels observed inside the truncation band (same pixel
+ *                             and depth tests as tsdf_integrate*) take evidence from the label image
+ *   tsdf_download_labels      copy the three arrays out (any pointer may be NULL)
+ */
+int tsdf_labels_enable(tsdf_volume *vol, float prob_threshold);
+int tsdf_compose_labels(tsdf_volume *vol, const uint8_t *masks_dev, const uint16_t *labels_host,
+                        const float *scores_host, int32_t k, uint16_t *label_im_dev, float *score_im_dev);
+int tsdf_integrate_labels_device(tsdf_volume *vol, const float *depth_dev, const uint16_t *label_im_dev,
+                                 const float *score_im_dev, const float cam2world[16]);
+int tsdf_download_labels(tsdf_volume *vol, uint16_t *label_host, float *fp_host, float *bp_host);
+
+/*
  * Batched per-object fusion: the reference keeps one small TSDF per object instance and feeds
  * each of them depth * (its instance mask) for every keyframe (ref: src/Engine.cpp:172-233,
  * src/Object.cpp:67,143-166).  A batch owns n volumes (own grid, origin and base pose each; same

@@ -65,6 +65,13 @@ class Oracle:
                                         C.c_int, C.c_int, C.c_float, _f32p]
         L.oracle_mask_depth.argtypes = [_f32p, np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS"),
                                         C.c_int, _f32p]
+        u16p = np.ctypeslib.ndpointer(dtype=np.uint16, flags="C_CONTIGUOUS")
+        L.oracle_integrate_labels.restype = C.c_int64
+        L.oracle_integrate_labels.argtypes = [_f32p, _f32p, _f32p, u16p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                              C.c_float, C.c_float, u16p, _f32p, _f32p]
+        L.oracle_compose_labels.argtypes = [np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS"), u16p, _f32p,
+                                            C.c_int, C.c_int, u16p, _f32p]
         L.oracle_max_threads.restype = C.c_int
 
     # --- grid ---------------------------------------------------------------------------
@@ -160,6 +167,25 @@ class Oracle:
         out = np.empty_like(d)
         self.lib.oracle_mask_depth(d, np.ascontiguousarray(mask_u8, dtype=np.uint8), d.size, out)
         return out
+
+    # --- per-voxel label fusion (project-defined rule, see tsdf_oracle.c) ----------------------
+    def integrate_labels(self, K, cam2base, depth, label_im, score_im, dims, origin, voxel_size, trunc,
+                         label, fp, bp, z_begin=0, z_end=None, max_depth=6.0, prob_thd=0.5):
+        dx, dy, dz = dims
+        z_end = dz if z_end is None else z_end
+        h, w = depth.shape
+        return int(self.lib.oracle_integrate_labels(
+            _f32(K).ravel(), _f32(cam2base).ravel(), _f32(depth), np.ascontiguousarray(label_im, np.uint16),
+            _f32(score_im), h, w, dx, dy, z_begin, z_end, origin[0], origin[1], origin[2], voxel_size, trunc,
+            max_depth, prob_thd, label, fp, bp))
+
+    def compose_labels(self, masks, labels, scores):
+        masks = np.ascontiguousarray(masks, np.uint8)
+        k, h, w = masks.shape
+        lab = np.empty((h, w), np.uint16)
+        sc = np.empty((h, w), np.float32)
+        self.lib.oracle_compose_labels(masks, np.ascontiguousarray(labels, np.uint16), _f32(scores), k, h * w, lab, sc)
+        return lab, sc
 
     def max_threads(self):
         return int(self.lib.oracle_max_threads())

@@ -340,6 +340,81 @@ void oracle_mask_depth(const float *depth, const uint8_t *mask, int n, float *ou
     for (int i = 0; i < n; ++i) out[i] = depth[i] * (mask[i] >= 128 ? 1.0f : 0.0f);
 }
 
+/* ------------------------------------------------------------------------------------
+ * Per-voxel semantic-label fusion (BASELINE config 5).  NOT in the reference's TSDF: the
+ * reference fuses instance evidence per sparse ObjectPoint -- Fp += score when a point is seen
+ * inside a mask of its object, Bp += score otherwise, P = Fp/(Fp+Bp), bad when P < threshold
+ * (ref: src/ObjectPoint.cpp:190-219, :149-154; threshold Engine.mProbThd = 0.5, config/TUM3.yaml:92).
+ * This project applies the same evidence rule per voxel; parity is against this restatement only.
+ *
+ * For every voxel that Integrate would update this frame (same geometry and depth tests,
+ * src/tsdf.cu:27-49) AND that lies inside the truncation band (diff < trunc), with
+ * l = label_im[pixel] (0 = no instance) and s = score_im[pixel]:
+ *     l == 0                     -> nothing
+ *     label == 0                 -> label = l, Fp = s, Bp = 0            (adopt)
+ *     label == l                 -> Fp = Fp + s
+ *     otherwise                  -> Bp = Bp + s; if Fp / (Fp + Bp) < thd: label = l, Fp = s, Bp = 0
+ * Returns the number of voxels whose label state changed.
+ * ---------------------------------------------------------------------------------- */
+int64_t oracle_integrate_labels(const float *cam_K, const float *cam2base, const float *depth_im,
+                                const uint16_t *label_im, const float *score_im, int im_height, int im_width,
+                                int dim_x, int dim_y, int z_begin, int z_end,
+                                float origin_x, float origin_y, float origin_z, float voxel_size,
+                                float trunc_margin, float max_depth, float prob_thd,
+                                uint16_t *label, float *fp, float *bp)
+{
+    int64_t n = 0;
+    for (int gz = z_begin; gz < z_end; ++gz)
+        for (int gy = 0; gy < dim_y; ++gy)
+            for (int gx = 0; gx < dim_x; ++gx) {
+                const int64_t i = ((int64_t)(gz - z_begin) * dim_y + gy) * dim_x + gx;
+                float bx = origin_x + (float)gx * voxel_size;
+                float by = origin_y + (float)gy * voxel_size;
+                float bz = origin_z + (float)gz * voxel_size;
+                float dx = bx - cam2base[3], dy = by - cam2base[7], dz = bz - cam2base[11];
+                float cx = cam2base[0] * dx + cam2base[4] * dy + cam2base[8] * dz;
+                float cy = cam2base[1] * dx + cam2base[5] * dy + cam2base[9] * dz;
+                float cz = cam2base[2] * dx + cam2base[6] * dy + cam2base[10] * dz;
+                if (cz <= 0.0f) continue;
+                float pu = roundf(cam_K[0] * (cx / cz) + cam_K[2]);
+                float pv = roundf(cam_K[4] * (cy / cz) + cam_K[5]);
+                if (!(pu >= 0.0f && pu < (float)im_width && pv >= 0.0f && pv < (float)im_height)) continue;
+                const int pix = (int)pv * im_width + (int)pu;
+                float d = depth_im[pix];
+                if (d <= 0.0f || d > max_depth) continue;
+                float diff = d - cz;
+                if (diff <= -trunc_margin) continue;
+                if (!(diff < trunc_margin)) continue;      /* free space in front of the surface: no label evidence */
+                const uint16_t l = label_im[pix];
+                if (l == 0) continue;
+                const float s = score_im[pix];
+                if (label[i] == 0) { label[i] = l; fp[i] = s; bp[i] = 0.0f; }
+                else if (label[i] == l) { fp[i] = fp[i] + s; }
+                else {
+                    bp[i] = bp[i] + s;
+                    if (fp[i] / (fp[i] + bp[i]) < prob_thd) { label[i] = l; fp[i] = s; bp[i] = 0.0f; }
+                }
+                ++n;
+            }
+    return n;
+}
+
+/* Label / score images from K instance masks in MaskRCNN's output format (uint8 {0,255} per mask,
+ * label 1..80, score; ref: src/MaskRCNN.cpp:316-362): per pixel the covering instance with the
+ * highest score wins, the lower index on ties; pixels no mask covers get label 0, score 0. */
+void oracle_compose_labels(const uint8_t *masks, const uint16_t *labels, const float *scores, int k,
+                           int n_pixels, uint16_t *label_im, float *score_im)
+{
+    for (int p = 0; p < n_pixels; ++p) {
+        uint16_t l = 0;
+        float s = 0.0f;
+        for (int m = 0; m < k; ++m)
+            if (masks[(int64_t)m * n_pixels + p] >= 128 && (l == 0 || scores[m] > s)) { l = labels[m]; s = scores[m]; }
+        label_im[p] = l;
+        score_im[p] = s;
+    }
+}
+
 int oracle_max_threads(void)
 {
 #ifdef _OPENMP

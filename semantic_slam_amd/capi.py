@@ -24,6 +24,7 @@ ABI_SYMBOLS = [
     "tsdf_count_surface", "tsdf_extract_surface", "tsdf_extract_crossings", "tsdf_save_ply", "tsdf_save_bin",
     "tsdf_integrate_sequence_timed", "tsdf_probe_stream", "tsdf_selftest_fastdiv", "tsdf_set_kernel_variant", "tsdf_last_error",
     "tsdf_version", "tsdf_multiply_matrix", "tsdf_invert_matrix",
+    "tsdf_labels_enable", "tsdf_compose_labels", "tsdf_integrate_labels_device", "tsdf_download_labels",
     "tsdf_batch_create", "tsdf_batch_destroy", "tsdf_batch_size", "tsdf_batch_volume",
     "tsdf_batch_integrate_device", "tsdf_batch_sync",
 ]
@@ -95,6 +96,10 @@ def load():
     L.tsdf_multiply_matrix.argtypes = [vp, vp, vp]
     L.tsdf_multiply_matrix.restype = None
     L.tsdf_invert_matrix.argtypes = [vp, vp]
+    L.tsdf_labels_enable.argtypes = [vp, C.c_float]
+    L.tsdf_compose_labels.argtypes = [vp, vp, vp, vp, C.c_int32, vp, vp]
+    L.tsdf_integrate_labels_device.argtypes = [vp, vp, vp, vp, vp]
+    L.tsdf_download_labels.argtypes = [vp, vp, vp, vp]
     L.tsdf_batch_create.argtypes = [C.POINTER(TsdfConfig), C.c_int32, C.POINTER(vp)]
     L.tsdf_batch_destroy.argtypes = [vp]
     L.tsdf_batch_size.argtypes = [vp]
@@ -311,6 +316,27 @@ class Volume:
 
     def set_kernel_variant(self, v):
         check(self.lib.tsdf_set_kernel_variant(self._h, v), "tsdf_set_kernel_variant")
+
+    # -- per-voxel label fusion ----------------------------------------------------------------
+    def labels_enable(self, prob_threshold=0.5):
+        check(self.lib.tsdf_labels_enable(self._h, prob_threshold), "tsdf_labels_enable")
+
+    def compose_labels(self, masks_ptr, labels, scores, label_im_ptr, score_im_ptr):
+        lab = np.ascontiguousarray(labels, np.uint16)
+        sc = _f32(scores)
+        check(self.lib.tsdf_compose_labels(self._h, masks_ptr, lab.ctypes.data, sc.ctypes.data, lab.size,
+                                           label_im_ptr, score_im_ptr), "tsdf_compose_labels")
+
+    def integrate_labels_device(self, depth_ptr, label_im_ptr, score_im_ptr, cam2world):
+        p = _f32(cam2world, 16)
+        check(self.lib.tsdf_integrate_labels_device(self._h, depth_ptr, label_im_ptr, score_im_ptr, p.ctypes.data),
+              "tsdf_integrate_labels_device")
+
+    def download_labels(self):
+        n = self.n_voxels
+        lab, fp, bp = np.empty(n, np.uint16), np.empty(n, np.float32), np.empty(n, np.float32)
+        check(self.lib.tsdf_download_labels(self._h, lab.ctypes.data, fp.ctypes.data, bp.ctypes.data), "tsdf_download_labels")
+        return lab, fp, bp
 
     # -- outputs ----------------------------------------------------------------------------
     def count_surface(self, weight_thresh=0.9):

@@ -24,6 +24,7 @@
 #include "pose_math.h"
 #include "tsdf_kernels.hip.h"
 #include "tsdf_multiframe.hip.h"
+#include "tsdf_labels.hip.h"
 #include "tsdf_extract.hip.h"
 
 namespace {
@@ -76,6 +77,10 @@ struct tsdf_volume {
     hipEvent_t frames_done[kStageSlots];
     bool frames_used[kStageSlots];
     int frames_next;
+    // per-voxel label fusion (allocated by tsdf_labels_enable)
+    uint16_t *d_label;
+    float *d_fp, *d_bp;
+    float prob_thd;
     // free-space summary (one word per 256-voxel row segment), see tsdf_kernels.hip.h
     uint32_t *d_flags;
     size_t n_flags;
@@ -500,6 +505,9 @@ int tsdf_destroy(tsdf_volume *v)
         if (v->d_frames[i]) (void)hipFree(v->d_frames[i]);
         if (v->frames_done[i]) (void)hipEventDestroy(v->frames_done[i]);
     }
+    if (v->d_label) (void)hipFree(v->d_label);
+    if (v->d_fp) (void)hipFree(v->d_fp);
+    if (v->d_bp) (void)hipFree(v->d_bp);
     if (v->d_scratch) (void)hipFree(v->d_scratch);
     if (v->d_flags) (void)hipFree(v->d_flags);
     if (v->d_tsdf) (void)hipFree(v->d_tsdf);
@@ -807,6 +815,82 @@ int tsdf_integrate_sequence_timed(tsdf_volume *v, const float *depth_dev, const 
     if (er != hipSuccess || es != hipSuccess || et != hipSuccess)
         return fail(TSDF_ERR_HIP, "tsdf_integrate_sequence_timed: event timing failed");
     *elapsed_ms = ms;
+    return TSDF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-voxel label fusion (csrc/tsdf_labels.hip.h)
+// ---------------------------------------------------------------------------------------------
+int tsdf_labels_enable(tsdf_volume *v, float prob_threshold)
+{
+    if (!v) return fail(TSDF_ERR_INVALID, "tsdf_labels_enable: NULL handle");
+    if (v->cfg.dim_x % 4 != 0) return fail(TSDF_ERR_INVALID, "tsdf_labels_enable: dim_x must be a multiple of 4");
+    int rc = bind_device(v);
+    if (rc) return rc;
+    v->prob_thd = prob_threshold;
+    const size_t n = (size_t)(v->n_vox > 0 ? v->n_vox : 1);
+    if (!v->d_label) {
+        HIP_TRY(hipMalloc((void **)&v->d_label, n * sizeof(uint16_t)));
+        HIP_TRY(hipMalloc((void **)&v->d_fp, n * sizeof(float)));
+        HIP_TRY(hipMalloc((void **)&v->d_bp, n * sizeof(float)));
+    }
+    HIP_TRY(hipMemsetAsync(v->d_label, 0, n * sizeof(uint16_t), v->stream));
+    HIP_TRY(hipMemsetAsync(v->d_fp, 0, n * sizeof(float), v->stream));
+    HIP_TRY(hipMemsetAsync(v->d_bp, 0, n * sizeof(float), v->stream));
+    return TSDF_OK;
+}
+
+int tsdf_integrate_labels_device(tsdf_volume *v, const float *depth_dev, const uint16_t *label_im_dev,
+                                 const float *score_im_dev, const float cam2world[16])
+{
+    if (!v || !depth_dev || !label_im_dev || !score_im_dev || !cam2world)
+        return fail(TSDF_ERR_INVALID, "tsdf_integrate_labels_device: NULL argument");
+    if (!v->d_label) return fail(TSDF_ERR_INVALID, "tsdf_integrate_labels_device: call tsdf_labels_enable first");
+    int rc = bind_device(v);
+    if (rc) return rc;
+    const int nz = v->cfg.z_end - v->cfg.z_begin;
+    if (nz == 0) return TSDF_OK;
+    float c2b[16];
+    compose_cam2base(v, cam2world, c2b);
+    tsdfk::LabelParams lp;
+    lp.g = make_params(v, depth_dev, nullptr, c2b, 4);
+    lp.label_im = label_im_dev; lp.score_im = score_im_dev;
+    lp.label = v->d_label; lp.fp = v->d_fp; lp.bp = v->d_bp; lp.prob_thd = v->prob_thd;
+    dim3 block(64, 4, 1), grid((lp.g.xgroups + 63) / 64, (v->cfg.dim_y + 3) / 4, nz);
+    hipLaunchKernelGGL(tsdfk::integrate_labels, grid, block, 0, v->stream, lp);
+    HIP_TRY(hipGetLastError());
+    return TSDF_OK;
+}
+
+int tsdf_download_labels(tsdf_volume *v, uint16_t *label_host, float *fp_host, float *bp_host)
+{
+    if (!v) return fail(TSDF_ERR_INVALID, "tsdf_download_labels: NULL handle");
+    if (!v->d_label) return fail(TSDF_ERR_INVALID, "tsdf_download_labels: labels not enabled");
+    int rc = bind_device(v);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(v->stream));
+    const size_t n = (size_t)v->n_vox;
+    if (n == 0) return TSDF_OK;
+    if (label_host) HIP_TRY(hipMemcpy(label_host, v->d_label, n * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    if (fp_host) HIP_TRY(hipMemcpy(fp_host, v->d_fp, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (bp_host) HIP_TRY(hipMemcpy(bp_host, v->d_bp, n * sizeof(float), hipMemcpyDeviceToHost));
+    return TSDF_OK;
+}
+
+int tsdf_compose_labels(tsdf_volume *v, const uint8_t *masks_dev, const uint16_t *labels_host, const float *scores_host,
+                        int32_t k, uint16_t *label_im_dev, float *score_im_dev)
+{
+    if (!v || !label_im_dev || !score_im_dev || k < 0 || (k > 0 && (!masks_dev || !labels_host || !scores_host)))
+        return fail(TSDF_ERR_INVALID, "tsdf_compose_labels: bad argument");
+    if (k > tsdfk::kMaxInstances) return fail(TSDF_ERR_INVALID, "tsdf_compose_labels: at most %d instances per frame", tsdfk::kMaxInstances);
+    int rc = bind_device(v);
+    if (rc) return rc;
+    tsdfk::ComposeParams c;
+    c.masks = masks_dev; c.label_im = label_im_dev; c.score_im = score_im_dev; c.k = k;
+    c.n_pixels = v->cfg.im_height * v->cfg.im_width;
+    for (int i = 0; i < tsdfk::kMaxInstances; ++i) { c.labels[i] = i < k ? labels_host[i] : 0; c.scores[i] = i < k ? scores_host[i] : 0.0f; }
+    hipLaunchKernelGGL(tsdfk::compose_labels, dim3((c.n_pixels + 255) / 256), dim3(256), 0, v->stream, c);
+    HIP_TRY(hipGetLastError());
     return TSDF_OK;
 }
 
