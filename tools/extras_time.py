@@ -1,0 +1,76 @@
+"""Development probe: time the "next" rows on one GPU next to the CPU oracle (512^3 S-surf scene):
+surface points (N1), zero-crossing vertices, label fusion (N3), raw-u16 ingest (N4)."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle.oracle import Oracle  # noqa: E402  (checker, timed here as the CPU baseline)
+from semantic_slam_amd import capi, synth  # noqa: E402
+
+D, vs = 512, 0.005
+dims = (D, D, D)
+origin = synth.surf_volume(D, vs, 1.0)
+cfg = capi.make_config(dims, vs, origin)
+scene = synth.SurfScene(dims, vs, origin)
+orc = Oracle()
+vol = capi.Volume(cfg)
+frames = [(scene.pose(k * 4, 64), scene.depth(scene.pose(k * 4, 64), quantize=True)) for k in range(4)]
+for c2w, d in frames:
+    vol.integrate(d, c2w)
+vol.sync()
+
+
+def timeit(fn, n=5):
+    fn()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        out = fn()
+    return (time.perf_counter() - t0) / n, out
+
+
+t, w = vol.download()
+tg, pts = timeit(vol.extract_surface)
+tc, ref = timeit(lambda: orc.surface_points(t, w, dims, vs, origin), 1)
+assert np.array_equal(pts, ref)
+print(f"surface points (ref rule): {len(pts)} points  GPU {tg * 1e3:.1f} ms (incl. D2H of the list)  CPU oracle {tc * 1e3:.0f} ms  x{tc / tg:.0f}")
+tg, xs = timeit(vol.extract_crossings)
+tc, ref = timeit(lambda: orc.zero_crossings(t, w, dims[:2], 0, D, vs, origin), 1)
+assert np.array_equal(xs, ref)
+print(f"zero-crossing vertices: {len(xs)} points  GPU {tg * 1e3:.1f} ms  CPU oracle {tc * 1e3:.0f} ms  x{tc / tg:.0f}")
+
+vol.labels_enable(0.5)
+rng = np.random.default_rng(0)
+masks = np.zeros((6, 480, 640), np.uint8)
+for m in range(6):
+    masks[m, 40 * m:40 * m + 250, 60 * m:60 * m + 300] = 255
+labels, scores = rng.integers(1, 81, 6).astype(np.uint16), rng.uniform(0.8, 1, 6).astype(np.float32)
+m_dev = torch.from_numpy(masks).cuda()
+lab_dev = torch.empty((480, 640), dtype=torch.uint16, device="cuda")
+sc_dev = torch.empty((480, 640), dtype=torch.float32, device="cuda")
+d_dev = torch.from_numpy(frames[0][1]).cuda()
+
+
+def label_pass():
+    vol.compose_labels(m_dev.data_ptr(), labels, scores, lab_dev.data_ptr(), sc_dev.data_ptr())
+    vol.integrate_labels_device(d_dev.data_ptr(), lab_dev.data_ptr(), sc_dev.data_ptr(), frames[0][0])
+    vol.sync()
+
+
+tg, _ = timeit(label_pass, 20)
+li, si = orc.compose_labels(masks, labels, scores)
+L, F, B = np.zeros(D ** 3 // 8, np.uint16), np.zeros(D ** 3 // 8, np.float32), np.zeros(D ** 3 // 8, np.float32)
+t0 = time.perf_counter()
+orc.integrate_labels(cfg.cam_K, frames[0][0], frames[0][1], li, si, dims, origin, vs, cfg.trunc_margin, L, F, B,
+                     z_begin=224, z_end=288)
+tc = (time.perf_counter() - t0) * 8
+print(f"label fusion pass (compose 6 masks + 512^3 sweep): GPU {tg * 1e3:.3f} ms = {D ** 3 / tg / 1e6:.0f} Mvox/s  "
+      f"CPU oracle (1 thread, 64-slice sample x8) {tc * 1e3:.0f} ms")
+
+raw = np.round(np.clip(frames[0][1], 0, 13.0) * 5000.0).astype(np.uint16)
+tu, _ = timeit(lambda: (vol.integrate_u16(raw, frames[0][0]), vol.sync()), 50)
+tf, _ = timeit(lambda: (vol.integrate(frames[0][1], frames[0][0]), vol.sync()), 50)
+print(f"host-depth frame, synchronous per frame: raw u16 path {tu * 1e3:.3f} ms, fp32 path {tf * 1e3:.3f} ms")
