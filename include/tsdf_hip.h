@@ -234,6 +234,13 @@ int tsdf_probe_stream(tsdf_volume *vol, int32_t non_temporal, int32_t n_iters, f
  */
 int tsdf_selftest_fastdiv(int32_t device, uint64_t seed, uint64_t n_samples, uint64_t *mismatches, float first_bad[4]);
 
+/*
+ * Exhaustive device self-test of the kernel's one-instruction pixel rounding (v_cvt_rpi_i32_f32)
+ * against roundf for every fp32 value in (-0.5, 2^24].  *mismatches must come back 0;
+ * first_bad = {u, got, want, 0} otherwise.
+ */
+int tsdf_selftest_round(int32_t device, uint64_t *mismatches, float first_bad[4]);
+
 /* Select the Integrate kernel variant (0 = default; others are listed in DESIGN.md). */
 int tsdf_set_kernel_variant(tsdf_volume *vol, int32_t variant);
 

@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "tsdf_sync", "tsdf_download", "tsdf_copy_slices", "tsdf_upload", "tsdf_refresh_summary", "tsdf_device_ptrs", "tsdf_slab_voxels",
     "tsdf_get_config", "tsdf_last_cam2base", "tsdf_set_stream", "tsdf_get_stream",
     "tsdf_count_surface", "tsdf_extract_surface", "tsdf_extract_crossings", "tsdf_save_ply", "tsdf_save_bin",
-    "tsdf_integrate_sequence_timed", "tsdf_probe_stream", "tsdf_selftest_fastdiv", "tsdf_set_kernel_variant", "tsdf_last_error",
+    "tsdf_integrate_sequence_timed", "tsdf_probe_stream", "tsdf_selftest_fastdiv", "tsdf_selftest_round", "tsdf_set_kernel_variant", "tsdf_last_error",
     "tsdf_version", "tsdf_multiply_matrix", "tsdf_invert_matrix",
     "tsdf_labels_enable", "tsdf_compose_labels", "tsdf_integrate_labels_device", "tsdf_download_labels",
     "tsdf_batch_create", "tsdf_batch_destroy", "tsdf_batch_size", "tsdf_batch_volume",
@@ -90,6 +90,7 @@ def load():
     L.tsdf_integrate_sequence_timed.argtypes = [vp, vp, vp, C.c_int32, f32p]
     L.tsdf_probe_stream.argtypes = [vp, C.c_int32, C.c_int32, f32p]
     L.tsdf_selftest_fastdiv.argtypes = [C.c_int32, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), f32p]
+    L.tsdf_selftest_round.argtypes = [C.c_int32, C.POINTER(C.c_uint64), f32p]
     L.tsdf_set_kernel_variant.argtypes = [vp, C.c_int32]
     L.tsdf_last_error.restype = C.c_char_p
     L.tsdf_version.restype = C.c_char_p
@@ -169,6 +170,14 @@ def selftest_fastdiv(n_samples, seed=1, device=0):
     cnt = C.c_uint64()
     bad = (C.c_float * 4)()
     check(load().tsdf_selftest_fastdiv(device, seed, n_samples, C.byref(cnt), bad), "tsdf_selftest_fastdiv")
+    return cnt.value, list(bad)
+
+
+def selftest_round(device=0):
+    """Returns (mismatches, first_bad[4]) of the exhaustive pixel-rounding self-test."""
+    cnt = C.c_uint64()
+    bad = (C.c_float * 4)()
+    check(load().tsdf_selftest_round(device, C.byref(cnt), bad), "tsdf_selftest_round")
     return cnt.value, list(bad)
 
 

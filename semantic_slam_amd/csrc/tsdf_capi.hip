@@ -762,6 +762,29 @@ int tsdf_selftest_fastdiv(int32_t device, uint64_t seed, uint64_t n_samples, uin
     return TSDF_OK;
 }
 
+int tsdf_selftest_round(int32_t device, uint64_t *mismatches, float first_bad[4])
+{
+    if (!mismatches || !first_bad) return fail(TSDF_ERR_INVALID, "tsdf_selftest_round: NULL argument");
+    HIP_TRY(hipSetDevice(device));
+    unsigned long long *d_cnt = nullptr;
+    float *d_bad = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_cnt, sizeof *d_cnt));
+    HIP_TRY(hipMalloc((void **)&d_bad, 4 * sizeof(float)));
+    HIP_TRY(hipMemset(d_cnt, 0, sizeof *d_cnt));
+    HIP_TRY(hipMemset(d_bad, 0, 4 * sizeof(float)));
+    hipLaunchKernelGGL(tsdfk::selftest_round, dim3(256 * 8), dim3(256), 0, 0, d_cnt, d_bad);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    unsigned long long cnt = 0;
+    if (e == hipSuccess) e = hipMemcpy(&cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(first_bad, d_bad, 4 * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d_cnt);
+    (void)hipFree(d_bad);
+    if (e != hipSuccess) return fail(TSDF_ERR_HIP, "tsdf_selftest_round: %s", hipGetErrorString(e));
+    *mismatches = cnt;
+    return TSDF_OK;
+}
+
 int tsdf_probe_stream(tsdf_volume *v, int32_t non_temporal, int32_t n_iters, float *elapsed_ms)
 {
     if (!v || n_iters <= 0 || !elapsed_ms) return fail(TSDF_ERR_INVALID, "tsdf_probe_stream: bad argument");

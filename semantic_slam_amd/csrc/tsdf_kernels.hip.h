@@ -220,6 +220,20 @@ __device__ __forceinline__ v2f fast_div2(v2f n, float d)
     return __builtin_elementwise_fma(e2, R, q1);
 }
 
+// roundf(u) for u > -0.5, as an integer, in ONE instruction: v_cvt_rpi_i32_f32 computes
+// (int)floor(u + 0.5) with a single rounding (round to nearest, ties toward +infinity) -- for
+// u > -0.5 that is exactly C's round-half-away-from-zero (ref: src/tsdf.cu:41-42 `roundf`), for
+// huge u it saturates (and is then rejected by the range test), and u <= -0.5 / NaN are rejected
+// by the `u > -0.5` test before the value is used.  It replaces trunc, subtract, compare, select,
+// add and convert (6 instructions per coordinate).  There is no builtin, hence the one-line asm;
+// tsdf_selftest_round checks it against roundf for EVERY float in (-0.5, 2^24] on the device.
+__device__ __forceinline__ int round_half_up_i32(float u)
+{
+    int r;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(u));
+    return r;
+}
+
 // Denominators the fast path accepts; numerators are bounded by the host (IntegrateParams::fast_ok).
 #define TSDF_FAST_D_MIN 8.6736174e-19f   /* 2^-60 */
 
@@ -403,9 +417,9 @@ __device__ __forceinline__ void integrate_tile_body(const IntegrateParams &p, co
         // Same values as the generic branch below, obtained with fewer instructions:
         //  - both quotients of a voxel from one refined reciprocal (fast_div2), packed;
         //  - (cx, cy) sums, fx*q + cx / fy*q + cy as two-wide packed operations;
-        //  - roundf(u) for u > -0.5 is trunc(u) + (u - trunc(u) >= 0.5); u <= -0.5 (and NaN) can
-        //    only round to a negative pixel, which ref: src/tsdf.cu:43 rejects -- so the lower
-        //    bound is tested on u itself and the sign handling of roundf is not needed.
+        //  - roundf(u) as one v_cvt_rpi_i32_f32 (round_half_up_i32 above); u <= -0.5 (and NaN) can
+        //    only round to a negative pixel, which ref: src/tsdf.cu:43 rejects -- so the lower bound
+        //    is tested on u itself, the upper one on the integer (unsigned compare).
         const v2f F = {p.fx, p.fy}, C = {p.cx, p.cy};
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -419,15 +433,12 @@ __device__ __forceinline__ void integrate_tile_body(const IntegrateParams &p, co
                 const v2f n = A + XY1 + XY2;                       // (pt_cam_x, pt_cam_y), ref: :36-37
                 const float cz = pcz[r][j];
                 const v2f uv = F * fast_div2(n, cz) + C;           // ref: :41-42 before rounding
-                const v2f tr = {__builtin_truncf(uv.x), __builtin_truncf(uv.y)};
-                const v2f fr = uv - tr;                            // exact
-                const v2f rd = {tr.x + (fr.x >= 0.5f ? 1.0f : 0.0f), tr.y + (fr.y >= 0.5f ? 1.0f : 0.0f)};
-                const bool ok = row_ok && cz > 0.0f && uv.x > -0.5f && uv.y > -0.5f && rd.x < (float)p.W &&
-                                rd.y < (float)p.H;
+                const int iu = round_half_up_i32(uv.x), iv = round_half_up_i32(uv.y);
+                const bool ok = row_ok && cz > 0.0f && uv.x > -0.5f && uv.y > -0.5f &&
+                                (unsigned)iu < (unsigned)p.W && (unsigned)iv < (unsigned)p.H;
                 geo[r][j] = ok;
-                // rd.y*W + rd.x < 2^24 (fast_ok): one exact fma + one conversion
-                pixel[r][j] = ok ? (int)__builtin_fmaf(rd.y, (float)p.W, rd.x) : 0;
-                if constexpr (LDSD) { pix_u[r][j] = ok ? (int)rd.x : 0; pix_v[r][j] = ok ? (int)rd.y : 0; }
+                pixel[r][j] = ok ? iv * p.W + iu : 0;
+                if constexpr (LDSD) { pix_u[r][j] = ok ? iu : 0; pix_v[r][j] = ok ? iv : 0; }
             }
         }
     } else {
@@ -649,6 +660,25 @@ __global__ __launch_bounds__(256) void selftest_fastdiv(uint64_t seed, uint64_t 
                 first_bad[0] = bad0 ? n0 : n1; first_bad[1] = d; first_bad[2] = bad0 ? q.x : q.y;
                 first_bad[3] = bad0 ? r0 : r1;
             }
+        }
+    }
+}
+
+// Exhaustive device check of round_half_up_i32 against roundf: every fp32 bit pattern with
+// -0.5 < u <= 2^24 (all of them, not a sample) must convert to the same integer.
+__global__ __launch_bounds__(256) void selftest_round(unsigned long long *mismatch, float *first_bad)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    // positive patterns 0 .. 0x4B800000 (2^24), then negative ones 0x80000000 .. 0xBEFFFFFF (-0 .. just above -0.5)
+    const uint64_t n_pos = 0x4B800001ull, n_neg = 0x3F000000ull;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pos + n_neg; i += stride) {
+        const uint32_t bits = i < n_pos ? (uint32_t)i : (0x80000000u + (uint32_t)(i - n_pos));
+        const float u = __uint_as_float(bits);
+        if (!(u > -0.5f)) continue;
+        const int want = (int)roundf(u);
+        const int got = round_half_up_i32(u);
+        if (got != want) {
+            if (atomicAdd(mismatch, 1ull) == 0ull) { first_bad[0] = u; first_bad[1] = (float)got; first_bad[2] = (float)want; first_bad[3] = 0.f; }
         }
     }
 }

@@ -61,12 +61,11 @@ __global__ __launch_bounds__(256) void integrate_labels(LabelParams lp)
             const v2f A = {ax[j], ay[j]};
             const v2f n = A + XY1 + XY2;
             const v2f uv = F * fast_div2(n, pcz[j]) + C;
-            const v2f tr = {__builtin_truncf(uv.x), __builtin_truncf(uv.y)};
-            const v2f fr = uv - tr;
-            const v2f rd = {tr.x + (fr.x >= 0.5f ? 1.0f : 0.0f), tr.y + (fr.y >= 0.5f ? 1.0f : 0.0f)};
-            const bool ok = pcz[j] > 0.0f && uv.x > -0.5f && uv.y > -0.5f && rd.x < (float)p.W && rd.y < (float)p.H;
+            const int iu = round_half_up_i32(uv.x), iv = round_half_up_i32(uv.y);
+            const bool ok = pcz[j] > 0.0f && uv.x > -0.5f && uv.y > -0.5f && (unsigned)iu < (unsigned)p.W &&
+                            (unsigned)iv < (unsigned)p.H;
             geo[j] = ok;
-            pixel[j] = ok ? (int)__builtin_fmaf(rd.y, (float)p.W, rd.x) : 0;
+            pixel[j] = ok ? iv * p.W + iu : 0;
         }
     } else {
 #pragma unroll

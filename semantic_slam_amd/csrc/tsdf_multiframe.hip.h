@@ -108,14 +108,11 @@ __global__ __launch_bounds__(256) void integrate_multi(MultiParams mp)
                     const v2f n = A + XY1 + XY2;
                     const float cz = pcz[r][j];
                     const v2f uv = F * fast_div2(n, cz) + C;
-                    const v2f tr = {__builtin_truncf(uv.x), __builtin_truncf(uv.y)};
-                    const v2f fr = uv - tr;
-                    const v2f rd = {tr.x + (fr.x >= 0.5f ? 1.0f : 0.0f), tr.y + (fr.y >= 0.5f ? 1.0f : 0.0f)};
-                    const bool ok = row_ok && cz > 0.0f && uv.x > -0.5f && uv.y > -0.5f && rd.x < (float)p.W &&
-                                    rd.y < (float)p.H;
+                    const int iu = round_half_up_i32(uv.x), iv = round_half_up_i32(uv.y);
+                    const bool ok = row_ok && cz > 0.0f && uv.x > -0.5f && uv.y > -0.5f &&
+                                    (unsigned)iu < (unsigned)p.W && (unsigned)iv < (unsigned)p.H;
                     geo[r][j] = ok;
-                    // rd.y*W + rd.x < 2^24 (fast_ok): one exact fma + one conversion
-                pixel[r][j] = ok ? (int)__builtin_fmaf(rd.y, (float)p.W, rd.x) : 0;
+                    pixel[r][j] = ok ? iv * p.W + iu : 0;
                 }
             }
         } else {

@@ -68,3 +68,36 @@ def test_object_callsite_sequence(cuda, oracle, tmp_path):
     oracle.save_bin(str(tmp_path / "want.bin"), ref_t, dims, origin, vs, trunc)
     assert (tmp_path / f"tsdf{vol_id}.bin").read_bytes() == (tmp_path / "want.bin").read_bytes()
     assert (tmp_path / f"tsdf{vol_id}.ply").read_bytes() == (tmp_path / "want.ply").read_bytes()
+
+
+def test_tsdffusion_native_backend(cuda, oracle, tmp_path):
+    """class TSDFfusion over the native library: the volume of the reference's Python glue
+    ([0,10]^3 m at 0.02 m = 500^3, world frame, TUM intrinsics; ref: src/TSDFfusion.py.in:19-29) fed
+    through the C++ class, point cloud compared with the oracle applying the reference's GpuIntegrate
+    rule to the same volume.  (The third-party package's own arithmetic is absent: parity unpinned.)"""
+    exe = str(tmp_path / "dropin_tsdffusion")
+    subprocess.check_call(["g++", "-O1", "-std=c++11", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "dropin_tsdffusion.cpp"), "-o", exe,
+                           "-L", PKG, "-ltsdf_dropin", "-ltsdf_hip", f"-Wl,-rpath,{PKG}"])
+    dims, vs = (500, 500, 500), 0.02
+    origin = np.zeros(3, np.float32)
+    # a camera inside the [0,10]^3 room looking along +z at a sphere + wall scene placed in front of it
+    scene = synth.SurfScene((200, 200, 200), 0.02, np.array([3.0, 3.0, 3.0], np.float32))
+    frames = []
+    for k in range(2):
+        pose = synth.make_pose(synth.rot_y(0.05 * k), [5.0 + 0.1 * k, 5.0, 0.5])
+        frames.append((pose, scene.depth(pose, quantize=True)))
+    inp = tmp_path / "frames.bin"
+    with open(inp, "wb") as f:
+        f.write(struct.pack("<i", len(frames)))
+        for pose, d in frames:
+            f.write(pose.astype(np.float32).tobytes())
+            f.write(d.astype(np.float32).tobytes())
+    out = tmp_path / "cloud.ply"
+    subprocess.check_call([exe, str(inp), str(out)], cwd=str(tmp_path))
+    t, w = oracle.init_grid(dims)
+    for pose, d in frames:
+        oracle.integrate(synth.TUM_K, pose, d, dims, origin, vs, float(np.float32(vs) * np.float32(5)), t, w)
+    assert w.sum() > 10000
+    oracle.save_ply(str(tmp_path / "want.ply"), t, w, dims, vs, origin)
+    assert out.read_bytes() == (tmp_path / "want.ply").read_bytes()

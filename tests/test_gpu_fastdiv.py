@@ -13,3 +13,9 @@ pytestmark = pytest.mark.gpu
 def test_fast_division_is_ieee_exact(cuda, seed):
     bad, first = capi.selftest_fastdiv(1 << 30, seed=seed)
     assert bad == 0, f"{bad} mismatches, first: n={first[0]!r} d={first[1]!r} got={first[2]!r} want={first[3]!r}"
+
+
+def test_one_instruction_rounding_equals_roundf_everywhere(cuda):
+    """v_cvt_rpi_i32_f32 == (int)roundf for EVERY fp32 value in (-0.5, 2^24] (exhaustive, ~2.3e9 values)."""
+    bad, first = capi.selftest_round()
+    assert bad == 0, f"{bad} mismatches, first: u={first[0]!r} got={first[1]!r} want={first[2]!r}"
