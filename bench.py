@@ -168,28 +168,34 @@ def main():
     n_upd_per_launch = upd_total / n_frames
     del t_host, w_host
 
-    # --- roofline of the dominant kernel (integrate_tile) on this rank -------------------------
-    # Bytes the frame must move (DESIGN.md "Bytes model"): per updated voxel 4 B weight read + 4 B
-    # weight write; the TSDF value is read only where the free-space summary does not already say
-    # "this 256-voxel segment is all ones" and written only where it changes; plus the summary
-    # words themselves, one pass over the depth frame and the parameters.  SURVEY.md section 8(d)
-    # counted 16 B for every updated voxel; that figure is reported beside it.
+    # --- roofline of the dominant kernel on this rank ---------------------------------------------
+    # The default path applies FPL = 4 consecutive frames per pass over the volume (integrate_multi):
+    # one launch = FPL steps.  Bytes one launch must move (DESIGN.md "Bytes model"): 4 B weight read +
+    # 4 B weight write per voxel touched by any of its frames; the TSDF value is read only where the
+    # free-space summary does not already say "this 256-voxel segment is all ones" and written only
+    # where it changes; the summary words; FPL passes over the depth frame; the parameters.
+    # SURVEY.md section 8(d) priced every updated voxel of every frame at 16 B; that figure is reported
+    # beside it, as is the plain streaming variant in which those 16 B really move.
     H, W = depth.shape
     v = args.variant
-    has_summary = v == 0 or 32 <= v < 64 or 80 <= v < 96
+    fused = v in (0, 4)
+    fpl = 4 if fused else 1
+    launches = (args.steps + fpl - 1) // fpl
+    has_summary = v in (0, 3, 4) or 32 <= v < 64 or 80 <= v < 96 or v >= 112
     has_elide = has_summary or v in (18, 19, 22, 23, 26, 27) or v >= 64
+    n_touched = min(float(n_slab), fpl * n_upd_per_launch)   # exact for sfull; upper bound otherwise
     if args.workload == "sfull":
-        # every voxel updated, every TSDF value stays exactly 1 (asserted above)
-        n_t_read = 0.0 if has_summary else n_upd_per_launch
-        n_t_written = 0.0 if has_elide else n_upd_per_launch
+        # every voxel updated every frame, every TSDF value stays exactly 1 (asserted above)
+        n_t_read = 0.0 if has_summary else n_touched
+        n_t_written = 0.0 if has_elide else n_touched
         count_note = "exact"
     else:
-        n_t_read = n_t_written = n_upd_per_launch
+        n_t_read = n_t_written = n_touched
         count_note = "upper bound (TSDF reads/writes elided on the device are not counted there)"
     flag_bytes = 4.0 * n_slab / 256.0 if has_summary else 0.0
-    bytes_per_launch = 8.0 * n_upd_per_launch + 4.0 * n_t_read + 4.0 * n_t_written + flag_bytes + 4.0 * H * W + 100.0
-    bytes_survey = 16.0 * n_upd_per_launch + 4.0 * H * W + 100.0
-    kernel_ms = kernel_ms_total / args.steps
+    bytes_per_launch = 8.0 * n_touched + 4.0 * n_t_read + 4.0 * n_t_written + flag_bytes + fpl * (4.0 * H * W + 100.0)
+    bytes_survey = fpl * (16.0 * n_upd_per_launch + 4.0 * H * W + 100.0)
+    kernel_ms = kernel_ms_total / launches
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
     achieved_survey = bytes_survey / (kernel_ms * 1e-3) / 1e9
 
@@ -203,7 +209,7 @@ def main():
     if os.path.isfile(tpath):
         try:
             rec = json.load(open(tpath))
-            key = f"{args.workload}_{D}_slab{ze - zb}"
+            key = f"{args.workload}_{D}_slab{ze - zb}" + ("" if args.variant == 0 else f"_v{args.variant}")
             if key in rec:
                 traffic = rec[key]["hbm_bytes_per_launch"]
         except Exception:
@@ -227,18 +233,25 @@ def main():
                    "kernel_variant": args.variant},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "kernel": "tsdfk::integrate_tile<R=2,ELIDE,NT,SUM,FAST>" if args.variant == 0 else f"variant {args.variant}",
+                     "kernel": "tsdfk::integrate_multi<1,true>" if fused else
+                               ("tsdfk::integrate_tile<2,true,true,false,true,false,true>" if v == 3 else f"variant {v}"),
+                     "frames_per_launch": fpl, "launches": launches,
                      "kernel_ms": round(kernel_ms, 5),
                      "algorithmic_bytes_per_launch": int(bytes_per_launch),
-                     "voxels_updated_per_launch": int(n_upd_per_launch),
+                     "voxel_updates_per_frame": int(n_upd_per_launch),
+                     "voxels_touched_per_launch": int(n_touched),
                      "tsdf_values_read_per_launch": int(n_t_read),
                      "tsdf_values_written_per_launch": int(n_t_written),
                      "tsdf_counts": count_note,
-                     "bytes_model": "8 B per updated voxel (weight r+w) + 4 B per TSDF value read + 4 B per TSDF value "
-                                    "written + 4 B per 256-voxel summary word + 4*H*W + 100",
+                     "bytes_model": "per launch of frames_per_launch frames: 8 B per voxel touched (weight r+w) + 4 B per "
+                                    "TSDF value read + 4 B per TSDF value written + 4 B per 256-voxel summary word + "
+                                    "frames_per_launch * (4*H*W + 100)",
+                     "binding_resource": "VALU issue, not HBM: the kernel moves a fraction of the bytes a 16 B/voxel "
+                                         "streamer would (profiles/r01_sfull512_sq_counters.json); see streaming_variant "
+                                         "for the access pattern's HBM rate when all bytes move",
                      "survey_16B_model": {"bytes_per_launch": int(bytes_survey), "achieved": round(achieved_survey, 1),
                                           "frac": round(achieved_survey / HBM_PEAK_GBS, 4)},
-                     "note": "per-rank slab launch; average over the timed steps from HIP events on the launch stream"},
+                     "note": "per-rank slab launch; kernel_ms = HIP-event time of the timed region / launches"},
     }
     if world == 1 and args.variant == 0 and args.emulate_world <= 1:
         # The same workload through the plain streaming variant (no elision, no summary: all 16 B per
