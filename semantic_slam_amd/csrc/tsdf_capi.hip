@@ -84,7 +84,9 @@ struct tsdf_volume {
     // free-space summary (one word per 256-voxel row segment), see tsdf_kernels.hip.h
     uint32_t *d_flags;
     size_t n_flags;
-    int nseg;
+    int nseg;              // chunks per row when dim_x % 256 == 0 (row-mapped kernels), else 0
+    int chunks_per_slice;  // ceil(dim_x*dim_y / 256)
+    bool flat;             // dim_x % 256 != 0: summary-maintaining launches use the flat mapping
     bool flags_known_zero;
     // scratch for surface extraction (allocated on first use)
     void *d_scratch;
@@ -99,11 +101,13 @@ struct tsdf_batch {
     // per-frame parameter blocks: pinned host ring -> device ring
     tsdfk::IntegrateParams *h_params[kStageSlots];
     tsdfk::IntegrateParams *d_params[kStageSlots];
+    tsdfk::FramePose *h_poses[kStageSlots];
+    tsdfk::FramePose *d_poses[kStageSlots];
     hipEvent_t slot_done[kStageSlots];
     bool slot_used[kStageSlots];
     int slot_next;
     int2 *d_slice_map;
-    int total_slices, max_bx, max_by;
+    int total_slices, max_blocks;
 };
 
 namespace {
@@ -136,6 +140,9 @@ tsdfk::IntegrateParams make_params(const tsdf_volume *v, const float *depth_dev,
     p.xgroups = (c.dim_x + vx - 1) / vx;
     p.flags = v->d_flags;
     p.nseg = v->nseg;
+    p.quads_per_row = c.dim_x / 4;
+    p.quads_per_slice = (int)((int64_t)c.dim_x * c.dim_y / 4);
+    p.chunks_per_slice = v->chunks_per_slice;
     // The shared-reciprocal projection (tsdf_kernels.hip.h, fast_div2) is exact when no operand
     // needs div_scale's pre-scaling: bound every camera-frame coordinate of the slab by
     // sum_j |R_ij| * max|d_j| and keep it, and the intrinsics, far from the exponent limits.
@@ -202,18 +209,17 @@ int drop_summary(tsdf_volume *v)
 int rebuild_summary(tsdf_volume *v)
 {
     if (v->n_flags == 0 || v->n_vox == 0) return TSDF_OK;
-    const long long rows = (long long)v->cfg.dim_y * (v->cfg.z_end - v->cfg.z_begin);
-    dim3 block(64, 4, 1);
-    dim3 grid(v->nseg, (unsigned)((rows + 3) / 4), 1);
-    if (rows > 4ll * 65535) {  // 2-D grid limit: fall back to "nothing known"
-        v->flags_known_zero = false;
-        return drop_summary(v);
-    }
-    hipLaunchKernelGGL(tsdfk::recompute_flags, grid, block, 0, v->stream, v->d_tsdf, v->d_weight, v->d_flags, v->cfg.dim_x, rows, v->nseg);
+    const int nz = v->cfg.z_end - v->cfg.z_begin;
+    const int qps = (int)((int64_t)v->cfg.dim_x * v->cfg.dim_y / 4);
+    dim3 block(64, 4, 1), grid((v->chunks_per_slice + 3) / 4, 1, nz);
+    hipLaunchKernelGGL(tsdfk::recompute_flags, grid, block, 0, v->stream, v->d_tsdf, v->d_weight, v->d_flags, qps,
+                       v->chunks_per_slice);
     HIP_TRY(hipGetLastError());
     v->flags_known_zero = false;
     return TSDF_OK;
 }
+
+int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *const *masks_dev, const float *c2b, int n);
 
 // Queue one Integrate launch.  Shapes are validated at tsdf_create, so the grid covers exactly
 // the slab and every access stays inside the two allocations.
@@ -227,6 +233,10 @@ int launch_integrate(tsdf_volume *v, const float *depth_dev, const uint8_t *mask
     int variant = v->variant;
     if (variant == 0 || variant == 3 || variant == 4) variant = kDefaultTile;
     if (c.dim_x % 4 != 0) variant = 1;  // rows are not 16-byte aligned: scalar kernel
+    if (v->flat && variant != 1 && variant != 2) {
+        // rows that are not a multiple of 256 voxels: the flat mapping (every lane busy, summary kept)
+        return launch_multi(v, &depth_dev, mask_dev ? &mask_dev : nullptr, c2b, 1);
+    }
     const int vx = variant == 1 ? 1 : 4;
     tsdfk::IntegrateParams p = make_params(v, depth_dev, mask_dev, c2b, vx);
     // which launches keep the free-space summary up to date: the SUM kernels (variants >= 32 and the
@@ -308,6 +318,32 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
     const tsdf_config &c = v->cfg;
     const int nz = c.z_end - c.z_begin;
     if (nz == 0 || n == 0) return TSDF_OK;
+    auto fill_pose = [&](tsdfk::FramePose &fp, int f) {
+        const tsdfk::IntegrateParams q = make_params(v, depth_dev[f], masks_dev ? masks_dev[f] : nullptr, c2b + 16 * f, 4);
+        fp.depth = q.depth; fp.mask = q.mask;
+        fp.rx0 = q.rx0; fp.rx1 = q.rx1; fp.rx2 = q.rx2;
+        fp.ry0 = q.ry0; fp.ry1 = q.ry1; fp.ry2 = q.ry2;
+        fp.rz0 = q.rz0; fp.rz1 = q.rz1; fp.rz2 = q.rz2;
+        fp.tx = q.tx; fp.ty = q.ty; fp.tz = q.tz;
+        fp.fast_ok = q.fast_ok; fp.cz_margin = q.cz_margin;
+    };
+    if (n == 1) {   // pose by value: nothing to stage
+        tsdfk::IntegrateParams common = make_params(v, depth_dev[0], nullptr, c2b, 4);
+        tsdfk::FramePose pose;
+        fill_pose(pose, 0);
+        std::memcpy(v->last_cam2base, c2b, sizeof v->last_cam2base);
+        v->flags_known_zero = false;
+        dim3 block(64, 4, 1);
+        if (v->flat) {
+            dim3 grid((v->chunks_per_slice + 3) / 4, 1, nz);
+            hipLaunchKernelGGL((tsdfk::integrate_multi_single<true, true>), grid, block, 0, v->stream, common, pose);
+        } else {
+            dim3 grid((common.xgroups + 63) / 64, (c.dim_y + 3) / 4, nz);
+            hipLaunchKernelGGL((tsdfk::integrate_multi_single<true, false>), grid, block, 0, v->stream, common, pose);
+        }
+        HIP_TRY(hipGetLastError());
+        return TSDF_OK;
+    }
     const int s = v->frames_next;
     v->frames_next = (s + 1) % kStageSlots;
     const size_t bytes = tsdfk::kMaxFramesPerLaunch * sizeof(tsdfk::FramePose);
@@ -321,26 +357,20 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
     mp.common = make_params(v, depth_dev[0], nullptr, c2b, 4);
     mp.frames = v->d_frames[s];
     mp.n_frames = n;
-    for (int f = 0; f < n; ++f) {
-        const tsdfk::IntegrateParams q = make_params(v, depth_dev[f], masks_dev ? masks_dev[f] : nullptr, c2b + 16 * f, 4);
-        tsdfk::FramePose &fp = v->h_frames[s][f];
-        fp.depth = q.depth; fp.mask = q.mask;
-        fp.rx0 = q.rx0; fp.rx1 = q.rx1; fp.rx2 = q.rx2;
-        fp.ry0 = q.ry0; fp.ry1 = q.ry1; fp.ry2 = q.ry2;
-        fp.rz0 = q.rz0; fp.rz1 = q.rz1; fp.rz2 = q.rz2;
-        fp.tx = q.tx; fp.ty = q.ty; fp.tz = q.tz;
-        fp.fast_ok = q.fast_ok; fp.cz_margin = q.cz_margin;
-    }
+    for (int f = 0; f < n; ++f) fill_pose(v->h_frames[s][f], f);
     HIP_TRY(hipMemcpyAsync(v->d_frames[s], v->h_frames[s], n * sizeof(tsdfk::FramePose), hipMemcpyHostToDevice, v->stream));
     std::memcpy(v->last_cam2base, c2b + 16 * (n - 1), sizeof v->last_cam2base);
     v->flags_known_zero = false;   // integrate_multi maintains the summary
     dim3 block(64, 4, 1);
-    if (v->variant == 4) {   // experiment: two rows per lane
+    if (v->flat) {
+        dim3 grid((v->chunks_per_slice + 3) / 4, 1, nz);
+        hipLaunchKernelGGL((tsdfk::integrate_multi<1, true, true>), grid, block, 0, v->stream, mp);
+    } else if (v->variant == 4) {   // experiment: two rows per lane
         dim3 grid((mp.common.xgroups + 63) / 64, (c.dim_y + 7) / 8, nz);
-        hipLaunchKernelGGL((tsdfk::integrate_multi<2, true>), grid, block, 0, v->stream, mp);
+        hipLaunchKernelGGL((tsdfk::integrate_multi<2, true, false>), grid, block, 0, v->stream, mp);
     } else {
         dim3 grid((mp.common.xgroups + 63) / 64, (c.dim_y + 3) / 4, nz);
-        hipLaunchKernelGGL((tsdfk::integrate_multi<1, true>), grid, block, 0, v->stream, mp);
+        hipLaunchKernelGGL((tsdfk::integrate_multi<1, true, false>), grid, block, 0, v->stream, mp);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(v->frames_done[s], v->stream));
@@ -472,8 +502,10 @@ int tsdf_create(const tsdf_config *cfg, tsdf_volume **out)
     if ((e = hipMalloc((void **)&v->d_tsdf, bytes)) != hipSuccess ||
         (e = hipMalloc((void **)&v->d_weight, bytes)) != hipSuccess)
         return cleanup(fail(TSDF_ERR_HIP, "tsdf_create: hipMalloc of %zu bytes x2: %s", bytes, hipGetErrorString(e)));
-    v->nseg = (cfg->dim_x + 255) / 256;
-    v->n_flags = (size_t)v->nseg * cfg->dim_y * (size_t)(cfg->z_end - cfg->z_begin);
+    v->flat = cfg->dim_x % 256 != 0;
+    v->nseg = v->flat ? 0 : cfg->dim_x / 256;
+    v->chunks_per_slice = (int)(((int64_t)cfg->dim_x * cfg->dim_y + 255) / 256);
+    v->n_flags = cfg->dim_x % 4 == 0 ? (size_t)v->chunks_per_slice * (size_t)(cfg->z_end - cfg->z_begin) : 0;
     if ((e = hipMalloc((void **)&v->d_flags, (v->n_flags ? v->n_flags : 1) * sizeof(uint32_t))) != hipSuccess)
         return cleanup(fail(TSDF_ERR_HIP, "tsdf_create: hipMalloc of the summary: %s", hipGetErrorString(e)));
     size_t img = (size_t)cfg->im_height * cfg->im_width * sizeof(float);
@@ -931,6 +963,8 @@ int tsdf_batch_destroy(tsdf_batch *b)
     for (int i = 0; i < kStageSlots; ++i) {
         if (b->h_params[i]) (void)hipHostFree(b->h_params[i]);
         if (b->d_params[i]) (void)hipFree(b->d_params[i]);
+        if (b->h_poses[i]) (void)hipHostFree(b->h_poses[i]);
+        if (b->d_poses[i]) (void)hipFree(b->d_poses[i]);
         if (b->slot_done[i]) (void)hipEventDestroy(b->slot_done[i]);
     }
     if (b->d_slice_map) (void)hipFree(b->d_slice_map);
@@ -954,8 +988,11 @@ int tsdf_batch_create(const tsdf_config *cfgs, int32_t n, tsdf_batch **out)
     if (!b) return fail(TSDF_ERR_INVALID, "tsdf_batch_create: out of host memory");
     b->device = cfgs[0].device;
     b->stream = nullptr; b->d_slice_map = nullptr; b->slot_next = 0;
-    b->total_slices = b->max_bx = b->max_by = 0;
-    for (int i = 0; i < kStageSlots; ++i) { b->h_params[i] = nullptr; b->d_params[i] = nullptr; b->slot_done[i] = nullptr; b->slot_used[i] = false; }
+    b->total_slices = b->max_blocks = 0;
+    for (int i = 0; i < kStageSlots; ++i) {
+        b->h_params[i] = nullptr; b->d_params[i] = nullptr; b->h_poses[i] = nullptr; b->d_poses[i] = nullptr;
+        b->slot_done[i] = nullptr; b->slot_used[i] = false;
+    }
     auto cleanup = [&](int code) { tsdf_batch_destroy(b); return code; };
     std::vector<int2> map;
     for (int i = 0; i < n; ++i) {
@@ -964,12 +1001,11 @@ int tsdf_batch_create(const tsdf_config *cfgs, int32_t n, tsdf_batch **out)
         if (rc) return cleanup(rc);
         b->vols.push_back(v);
         const int nz = cfgs[i].z_end - cfgs[i].z_begin;
-        for (int z = 0; z < nz; z += tsdfk::kBatchZ) map.push_back(make_int2(i, z));
-        b->max_bx = std::max(b->max_bx, (cfgs[i].dim_x / 4 + 63) / 64);
-        b->max_by = std::max(b->max_by, (cfgs[i].dim_y + 7) / 8);   // R = 2: 8 rows per workgroup
+        for (int z = 0; z < nz; ++z) map.push_back(make_int2(i, z));
+        b->max_blocks = std::max(b->max_blocks, (v->chunks_per_slice + 3) / 4);
     }
     b->total_slices = (int)map.size();
-    if (b->total_slices > 65535) return cleanup(fail(TSDF_ERR_INVALID, "tsdf_batch_create: %d slice chunks in total exceed the launch limit 65535", b->total_slices));
+    if (b->total_slices > 65535) return cleanup(fail(TSDF_ERR_INVALID, "tsdf_batch_create: %d slices in total exceed the launch limit 65535", b->total_slices));
     hipError_t e = hipSetDevice(b->device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
     if (e == hipSuccess && !map.empty()) e = hipMalloc((void **)&b->d_slice_map, map.size() * sizeof(int2));
@@ -977,6 +1013,8 @@ int tsdf_batch_create(const tsdf_config *cfgs, int32_t n, tsdf_batch **out)
     for (int i = 0; i < kStageSlots && e == hipSuccess; ++i) {
         e = hipHostMalloc((void **)&b->h_params[i], n * sizeof(tsdfk::IntegrateParams), hipHostMallocDefault);
         if (e == hipSuccess) e = hipMalloc((void **)&b->d_params[i], n * sizeof(tsdfk::IntegrateParams));
+        if (e == hipSuccess) e = hipHostMalloc((void **)&b->h_poses[i], n * sizeof(tsdfk::FramePose), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc((void **)&b->d_poses[i], n * sizeof(tsdfk::FramePose));
         if (e == hipSuccess) e = hipEventCreateWithFlags(&b->slot_done[i], hipEventDisableTiming);
     }
     if (e != hipSuccess) return cleanup(fail(TSDF_ERR_HIP, "tsdf_batch_create: %s", hipGetErrorString(e)));
@@ -1020,12 +1058,22 @@ int tsdf_batch_integrate_device(tsdf_batch *b, const float *depth_dev, const uin
         float c2b[16];
         compose_cam2base(v, cam2world, c2b);   // each object has its own base frame (ref: src/Object.cpp:23-29)
         std::memcpy(v->last_cam2base, c2b, sizeof c2b);
-        b->h_params[s][i] = make_params(v, depth_dev, masks_dev ? masks_dev[i] : nullptr, c2b, 4);
+        const tsdfk::IntegrateParams q = make_params(v, depth_dev, masks_dev ? masks_dev[i] : nullptr, c2b, 4);
+        b->h_params[s][i] = q;
+        tsdfk::FramePose &fp = b->h_poses[s][i];
+        fp.depth = q.depth; fp.mask = q.mask;
+        fp.rx0 = q.rx0; fp.rx1 = q.rx1; fp.rx2 = q.rx2;
+        fp.ry0 = q.ry0; fp.ry1 = q.ry1; fp.ry2 = q.ry2;
+        fp.rz0 = q.rz0; fp.rz1 = q.rz1; fp.rz2 = q.rz2;
+        fp.tx = q.tx; fp.ty = q.ty; fp.tz = q.tz;
+        fp.fast_ok = q.fast_ok; fp.cz_margin = q.cz_margin;
         v->flags_known_zero = false;           // the batched kernel maintains the summary
     }
     HIP_TRY(hipMemcpyAsync(b->d_params[s], b->h_params[s], n * sizeof(tsdfk::IntegrateParams), hipMemcpyHostToDevice, b->stream));
-    dim3 block(64, 4, 1), grid(b->max_bx, b->max_by, b->total_slices);
-    hipLaunchKernelGGL((tsdfk::integrate_tile_batched<2, true>), grid, block, 0, b->stream, b->d_params[s], b->d_slice_map);
+    HIP_TRY(hipMemcpyAsync(b->d_poses[s], b->h_poses[s], n * sizeof(tsdfk::FramePose), hipMemcpyHostToDevice, b->stream));
+    dim3 block(64, 4, 1), grid(b->max_blocks, 1, b->total_slices);
+    hipLaunchKernelGGL((tsdfk::integrate_multi_batched<true>), grid, block, 0, b->stream, b->d_params[s], b->d_poses[s],
+                       b->d_slice_map);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(b->slot_done[s], b->stream));
     b->slot_used[s] = true;

@@ -44,7 +44,13 @@ struct IntegrateParams {
     // both hold after tsdf_create/tsdf_reset; bit 0 is cleared by the first update that leaves a
     // value != 1; both are rebuilt from the arrays after tsdf_upload (recompute_flags)
     uint32_t *flags;
-    int nseg;               // ceil(dim_x / 256)
+    int nseg;               // segments per row = dim_x / 256 (row-mapped kernels; dim_x % 256 == 0 only)
+    // Linear ("flat") view of a slice, used by the kernels that serve any dim_x % 4 == 0: a slice is
+    // quads_per_slice = dim_x*dim_y/4 consecutive quads, a wavefront owns 64 consecutive quads (one
+    // "chunk" = 256 voxels, possibly spanning rows), the summary word of chunk c of slice z is
+    // flags[z * chunks_per_slice + c].  For dim_x % 256 == 0 a chunk IS a row segment, so both
+    // mappings address the same words.
+    int quads_per_row, quads_per_slice, chunks_per_slice;
     // host-proved magnitude bounds that make the shared-reciprocal projection exact (see fast_div2)
     int fast_ok;
     // |camera z| below which a lane's patch counts as "near the camera plane": far above the rounding
@@ -593,30 +599,6 @@ __global__ __launch_bounds__(256) void integrate_tile(IntegrateParams p)
     integrate_tile_body<R, ELIDE, NT, MASKED ? 1 : 0, SUM, EARLY, FAST, LDSD>(p, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
-// Many volumes, one frame, one launch (the reference's real usage: one small TSDF per object
-// instance, each fed depth x its own instance mask; ref: src/Engine.cpp:172-233, src/Object.cpp:67).
-// params[] holds one parameter block per object (own grid, origin, relative pose, mask, summary);
-// chunk_map[z] = {object, first slice} for every chunk of kBatchZ consecutive slices of every
-// object, so grid = (max x-blocks, max y-blocks, total chunks); a workgroup outside its object's
-// extent leaves at once, and the parameter block (read through a wave-uniform index: scalar
-// loads) is fetched once per kBatchZ slices.
-constexpr int kBatchZ = 1;
-
-template <int R, bool NT>
-__global__ __launch_bounds__(256) void integrate_tile_batched(const IntegrateParams *__restrict__ params,
-                                                              const int2 *__restrict__ chunk_map)
-{
-    const int2 m = chunk_map[blockIdx.z];
-    const IntegrateParams p = params[m.x];
-    if constexpr (kBatchZ == 1) {
-        integrate_tile_body<R, true, NT, 2, true, false, true>(p, blockIdx.x, blockIdx.y, m.y);
-    } else {
-        const int z_end = min(m.y + kBatchZ, p.nz);
-        for (int lz = m.y; lz < z_end; ++lz)
-            integrate_tile_body<R, true, NT, 2, true, false, true>(p, blockIdx.x, blockIdx.y, lz);
-    }
-}
-
 // Device self-test of fast_div2 against the compiler's IEEE division: pseudo-random operands from a
 // counter hash, denominators in [2^-60, 2^60], numerators up to 2^60 in magnitude (plus exact
 // zeros and structured mantissas).  A sample passes when the quotients are bit-identical, or --
@@ -701,24 +683,26 @@ __global__ __launch_bounds__(256) void stream_rmw(float *tsdf, float *weight, si
     }
 }
 
-// Rebuild the free-space summary from the TSDF array (after tsdf_upload or an external write):
-// one wavefront per 256-voxel row segment.  block = 64 x 4, grid = (nseg, ceil(rows/4)).
+// Rebuild the free-space summary from the arrays (after tsdf_upload or an external write): one
+// wavefront per 256-voxel chunk of a slice.  block = 64 x 4, grid = (ceil(chunks_per_slice/4), 1, nz).
 __global__ __launch_bounds__(256) void recompute_flags(const float *tsdf, const float *weight, uint32_t *flags,
-                                                       int dim_x, long long n_rows, int nseg)
+                                                       int quads_per_slice, int chunks_per_slice)
 {
-    const long long row = (long long)blockIdx.y * 4 + threadIdx.y;
-    if (row >= n_rows) return;
-    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int chunk = blockIdx.x * 4 + threadIdx.y;
+    if (chunk >= chunks_per_slice) return;
+    const int q = chunk * 64 + threadIdx.x;
+    const size_t base = ((size_t)blockIdx.z * quads_per_slice + q) * 4;
     bool ones = true, sane = true;
-    for (int j = 0; j < 4; ++j) {
-        if (x0 + j < dim_x) {
-            ones &= __float_as_uint(tsdf[(size_t)row * dim_x + x0 + j]) == 0x3f800000u;
-            const float w = weight[(size_t)row * dim_x + x0 + j];
-            sane &= (w >= 0.0f) && (w < 3.0e38f);
-        }
+    if (q < quads_per_slice) {
+        const float4 t = *reinterpret_cast<const float4 *>(tsdf + base);
+        const float4 w = *reinterpret_cast<const float4 *>(weight + base);
+        ones = __float_as_uint(t.x) == 0x3f800000u && __float_as_uint(t.y) == 0x3f800000u &&
+               __float_as_uint(t.z) == 0x3f800000u && __float_as_uint(t.w) == 0x3f800000u;
+        sane = w.x >= 0.0f && w.x < 3.0e38f && w.y >= 0.0f && w.y < 3.0e38f && w.z >= 0.0f && w.z < 3.0e38f &&
+               w.w >= 0.0f && w.w < 3.0e38f;
     }
     const uint32_t f = (__ballot(!ones) == 0ull ? 1u : 0u) | (__ballot(!sane) == 0ull ? 2u : 0u);
-    if (threadIdx.x == 0) flags[(size_t)row * nseg + blockIdx.x] = f;
+    if (threadIdx.x == 0) flags[(size_t)blockIdx.z * chunks_per_slice + chunk] = f;
 }
 
 // Raw 16-bit depth -> metres on the device: out = raw * scale where (row % row_step == 0 and

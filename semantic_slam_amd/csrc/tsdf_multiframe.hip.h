@@ -33,17 +33,34 @@ struct MultiParams {
     int n_frames;             // in the kernarg would be copied to registers and selected per frame)
 };
 
-template <int R, bool NT>
-__global__ __launch_bounds__(256) void integrate_multi(MultiParams mp)
+// FLAT: the lane's quad comes from the linear view of the slice (IntegrateParams::quads_per_slice):
+// wavefront = 64 consecutive quads in memory order, whatever dim_x % 4 == 0 is -- rows shorter than or
+// not a multiple of 256 voxels no longer leave lanes idle (200-voxel rows: 50 of 64 lanes in the row
+// mapping).  b0 = block index within the slice (4 chunks per block).  Needs R == 1.
+// !FLAT: the row mapping of integrate_tile (b0, b1 = x-block, y-block), dim_x % 256 == 0.
+template <int R, bool NT, bool FLAT>
+__device__ __forceinline__ void multi_body(const IntegrateParams &p, const FramePose *__restrict__ frames,
+                                           const int n_frames, const int b0, const int b1, const int lz)
 {
-    const IntegrateParams &p = mp.common;
-    const int bx = blockIdx.x, lz = blockIdx.z;
-    const int xg = bx * 64 + threadIdx.x;
-    const int gy0 = (blockIdx.y * 4 + threadIdx.y) * R;
-    if (xg >= p.xgroups || gy0 >= p.dim_y) return;
+    static_assert(!FLAT || R == 1, "the flat mapping handles one quad per lane");
+    int xg, gy0;
+    size_t row0, flag0;
+    if constexpr (FLAT) {
+        const int chunk = b0 * 4 + threadIdx.y;
+        const int q = chunk * 64 + threadIdx.x;
+        if (q >= p.quads_per_slice) return;
+        gy0 = q / p.quads_per_row;
+        xg = q - gy0 * p.quads_per_row;
+        row0 = ((size_t)lz * p.quads_per_slice + q) * 4;
+        flag0 = (size_t)lz * p.chunks_per_slice + chunk;
+    } else {
+        xg = b0 * 64 + threadIdx.x;
+        gy0 = (b1 * 4 + threadIdx.y) * R;
+        if (xg >= p.xgroups || gy0 >= p.dim_y) return;
+        row0 = ((size_t)lz * p.dim_y + gy0) * (size_t)p.dim_x + (size_t)xg * 4;
+        flag0 = ((size_t)lz * p.dim_y + gy0) * (size_t)p.nseg + b0;
+    }
     const int gz = p.z_begin + lz;
-    const size_t row0 = ((size_t)lz * p.dim_y + gy0) * (size_t)p.dim_x + (size_t)xg * 4;
-    const size_t flag0 = ((size_t)lz * p.dim_y + gy0) * (size_t)p.nseg + bx;
 
     // ---- voxel state held in registers across the frames ----------------------------------------
     uint32_t fl[R];
@@ -70,8 +87,8 @@ __global__ __launch_bounds__(256) void integrate_multi(MultiParams mp)
 
     // not unrolled: one frame's temporaries at a time (unrolling interleaves frames: 100 VGPRs)
 #pragma unroll 1
-    for (int f = 0; f < mp.n_frames; ++f) {
-        const FramePose q = mp.frames[f];   // wave-uniform address: scalar loads
+    for (int f = 0; f < n_frames; ++f) {
+        const FramePose q = frames[f];   // wave-uniform address: scalar loads
 
         // ---- geometry of frame f (ref: src/tsdf.cu:33-43) ------------------------------------------
         float ax[4], ay[4], az[4];
@@ -246,6 +263,36 @@ __global__ __launch_bounds__(256) void integrate_multi(MultiParams mp)
         }
         if ((fl[r] & 1u) && !ones[r]) p.flags[flag0 + (size_t)r * p.nseg] = fl[r] & 2u;
     }
+}
+
+template <int R, bool NT, bool FLAT>
+__global__ __launch_bounds__(256) void integrate_multi(MultiParams mp)
+{
+    multi_body<R, NT, FLAT>(mp.common, mp.frames, mp.n_frames, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// One frame, pose by value (no frame block in memory to stage): what a single tsdf_integrate* call
+// on a volume served by the flat mapping launches.
+template <bool NT, bool FLAT>
+__global__ __launch_bounds__(256) void integrate_multi_single(IntegrateParams p, FramePose pose)
+{
+    multi_body<1, NT, FLAT>(p, &pose, 1, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Many volumes, one frame, one launch (the reference's real usage: one small TSDF per object
+// instance, each fed depth x its own instance mask; ref: src/Engine.cpp:172-233, src/Object.cpp:67).
+// params[o] / poses[o]: the parameter block and this frame's relative pose + mask of object o (each has
+// its own base frame); slice_map[z] = {object, slice within it} for every slice of every object;
+// grid = (max blocks per slice, 1, total slices).  Flat mapping: object grids are small and rarely
+// 256 wide.  The blocks are read through a wave-uniform index (scalar loads).
+template <bool NT>
+__global__ __launch_bounds__(256) void integrate_multi_batched(const IntegrateParams *__restrict__ params,
+                                                               const FramePose *__restrict__ poses,
+                                                               const int2 *__restrict__ slice_map)
+{
+    const int2 m = slice_map[blockIdx.z];
+    const IntegrateParams p = params[m.x];
+    multi_body<1, NT, true>(p, poses + m.x, 1, blockIdx.x, 0, m.y);
 }
 
 }  // namespace tsdfk

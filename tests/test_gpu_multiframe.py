@@ -8,11 +8,12 @@ from semantic_slam_amd import capi, synth
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("dims", [(256, 42, 30), (200, 42, 30), (36, 20, 12)])   # row mapping, flat, flat + partial chunk
 @pytest.mark.parametrize("variant", [0, 4, 3])
 @pytest.mark.parametrize("n_frames", [1, 3, 4, 9])
-def test_fused_frames_equal_sequential_and_oracle(cuda, oracle, n_frames, variant):
-    dims, vs = (256, 42, 30), 0.008          # ragged row groups for R = 1 and R = 2
-    origin = synth.surf_volume(256, vs, 0.6)
+def test_fused_frames_equal_sequential_and_oracle(cuda, oracle, n_frames, variant, dims):
+    vs = 2.0 / dims[0]                       # ragged row groups for R = 1 and R = 2
+    origin = synth.surf_volume(dims[0], vs, 0.6)
     cfg = capi.make_config(dims, vs, origin)
     scene = synth.SurfScene(dims, vs, origin)
     rng = np.random.default_rng(n_frames)

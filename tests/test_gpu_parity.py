@@ -79,9 +79,10 @@ SUM_VARIANTS = [b + c for b in (32, 48, 64, 80, 96) for c in (2, 3, 6, 7, 10, 11
 def test_every_kernel_variant_is_bit_exact(cuda, oracle, variant):
     """All kernel variants (rows/tile, R = 1/2/4, elision on/off, nt on/off) give identical bits.
     The scene has free space (elided divisions), a truncation band and repeated frames, so both
-    sides of every wave-uniform shortcut are taken; dim_y = 50 leaves ragged row groups."""
-    dims, vs = (128, 50, 48), 0.01
-    origin = synth.surf_volume(128, vs, 0.7)
+    sides of every wave-uniform shortcut are taken; dim_y = 50 leaves ragged row groups.  dim_x = 256
+    keeps the row-mapped kernels in play (other widths are served by the flat mapping, tested above)."""
+    dims, vs = (256, 50, 24), 0.005
+    origin = synth.surf_volume(256, vs, 0.7)
     cfg = capi.make_config(dims, vs, origin)
     scene = synth.SurfScene(dims, vs, origin)
     ref_t, ref_w = oracle.init_grid(dims)
