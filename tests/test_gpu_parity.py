@@ -364,3 +364,33 @@ def test_full_size_512_surface_scene(cuda, oracle):
     frac = float(np.count_nonzero(ref_w)) / ref_w.size
     assert 0.05 < frac < 0.95, f"updated fraction {frac}: scene should mix updated and skipped voxels"
     assert_parity(got_t, got_w, ref_t, ref_w)
+
+
+def test_caller_owned_stream(cuda, oracle):
+    """tsdf_set_stream: the handle's work runs on a stream the caller owns (here a PyTorch stream), so
+    the caller's own events and synchronisation cover it."""
+    dims, vs = (64, 64, 32), 0.01
+    origin = synth.surf_volume(64, vs, 0.6)
+    cfg = capi.make_config(dims, vs, origin)
+    scene = synth.SurfScene(dims, vs, origin)
+    ref_t, ref_w = oracle.init_grid(dims)
+    stream = cuda.cuda.Stream()
+    with capi.Volume(cfg) as vol:
+        vol.set_stream(stream.cuda_stream)
+        with cuda.cuda.stream(stream):
+            for k in range(3):
+                c2w = scene.pose(k, n=5)
+                depth = scene.depth(c2w)
+                d_dev = cuda.from_numpy(depth).cuda()            # allocated and filled on `stream`
+                vol.integrate_device(d_dev.data_ptr(), c2w)
+                oracle.integrate(cfg.cam_K, c2w, depth, dims, origin, vs, cfg.trunc_margin, ref_t, ref_w)
+            done = cuda.cuda.Event()
+            done.record(stream)
+        done.synchronize()                                        # the caller's event waits for our kernels
+        t, w = vol.download()
+        vol.set_stream(None)                                      # back on the handle's own stream
+        vol.integrate(scene.depth(scene.pose(0, 5)), scene.pose(0, 5))
+        oracle.integrate(cfg.cam_K, scene.pose(0, 5), scene.depth(scene.pose(0, 5)), dims, origin, vs,
+                         cfg.trunc_margin, ref_t, ref_w)
+        t, w = vol.download()
+    assert_parity(t, w, ref_t, ref_w)
