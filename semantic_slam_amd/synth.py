@@ -147,3 +147,20 @@ def surf_volume(dim, voxel_size, z0=1.0):
 def random_pose(rng, max_angle=0.3, max_shift=0.3):
     ax, ay, az = rng.uniform(-max_angle, max_angle, 3)
     return make_pose(rot_z(az) @ rot_y(ay) @ rot_x(ax), rng.uniform(-max_shift, max_shift, 3))
+
+
+def look_at_pose(rng, target, distance, jitter=0.15):
+    """Camera at a random direction `distance` away from `target`, looking at it (optical axis = +z of the
+    camera, as in the pinhole model of ref: src/tsdf.cu:41-42), random roll, small angular jitter."""
+    d = rng.normal(size=3)
+    d /= np.linalg.norm(d) + 1e-12
+    pos = np.asarray(target, np.float64) - d * distance
+    z = d
+    up = rng.normal(size=3)
+    x = np.cross(up, z)
+    x /= np.linalg.norm(x) + 1e-12
+    y = np.cross(z, x)
+    R = np.stack([x, y, z], axis=1)                     # columns = camera axes in the base frame
+    a = rng.uniform(-jitter, jitter, 3)
+    R = R @ rot_z(a[2]) @ rot_y(a[1]) @ rot_x(a[0])
+    return make_pose(R, pos)
