@@ -62,7 +62,7 @@ def cpu_baseline(args, dims, vs, origin, cfg, depth, poses, n_upd_expected_per_s
             break
     out = {"value": round(nz * D * D * frames / el / 1e6, 1), "unit": "Mvoxels/s", "cores": threads,
            "kind": "port",
-           "sample": f"oracle/tsdf_oracle.c (OpenMP over z), {frames} frames of the same workload into "
+           "sample": f"oracle/tsdf_oracle.c (OpenMP over rows), {frames} frames of the same workload into "
                      f"z-slab [{zb},{zb + nz}) of the {D}^3 grid, {el:.1f} s"}
     if n_upd_expected_per_slice is not None:
         assert n_upd == frames * nz * n_upd_expected_per_slice, "S-full must update every voxel (N_upd == N)"
@@ -178,10 +178,10 @@ def main():
     # beside it, as is the plain streaming variant in which those 16 B really move.
     H, W = depth.shape
     v = args.variant
-    fused = v in (0, 4)
+    fused = v in (0, 4, 5)
     fpl = 4 if fused else 1
     launches = (args.steps + fpl - 1) // fpl
-    has_summary = v in (0, 3, 4) or 32 <= v < 64 or 80 <= v < 96 or v >= 112
+    has_summary = v in (0, 3, 4, 5) or 32 <= v < 64 or 80 <= v < 96 or v >= 112
     has_elide = has_summary or v in (18, 19, 22, 23, 26, 27) or v >= 64
     n_touched = min(float(n_slab), fpl * n_upd_per_launch)   # exact for sfull; upper bound otherwise
     if args.workload == "sfull":

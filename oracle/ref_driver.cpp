@@ -27,11 +27,11 @@ extern "C" void ref_integrate(float *cam_K, float *cam2base, float *depth_im, in
 {
 #ifdef _OPENMP
     if (n_threads <= 0) n_threads = omp_get_max_threads();
-#pragma omp parallel for schedule(static) num_threads(n_threads)
+#pragma omp parallel for collapse(2) schedule(static) num_threads(n_threads)
 #endif
     for (int z = 0; z < dim_z; ++z) {
-        blockIdx.x = z;
         for (int y = 0; y < dim_y; ++y) {
+            blockIdx.x = z;   /* one reference "thread" (z, y) at a time per host thread */
             threadIdx.x = y;
             GpuIntegrate(cam_K, cam2base, depth_im, im_height, im_width, dim_x, dim_y, dim_z,
                          origin_x, origin_y, origin_z, voxel_size, trunc_margin, tsdf, weight);

@@ -49,7 +49,8 @@ int64_t oracle_integrate(const float *cam_K, const float *cam2base, const float 
     (void)dim_z;
 #ifdef _OPENMP
     if (n_threads <= 0) n_threads = omp_get_max_threads();
-#pragma omp parallel for schedule(static) num_threads(n_threads) reduction(+ : n_updated)
+    /* rows (z, y) are independent: collapse both loops so that a thin slab still feeds every core */
+#pragma omp parallel for collapse(2) schedule(static) num_threads(n_threads) reduction(+ : n_updated)
 #else
     (void)n_threads;
 #endif

@@ -12,7 +12,8 @@
 // Bit parity: every fp32 operation keeps the reference's order (file compiled with
 // -ffp-contract=off, IEEE division, denormals on); the fast paths below only ever change
 // how a value the reference would also compute is obtained when that is provably the same
-// value (see "rounding-safe projection" in DESIGN.md), never the value itself.
+// value (exact elisions, shared-reciprocal projection, one-instruction rounding),
+// never the value itself.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

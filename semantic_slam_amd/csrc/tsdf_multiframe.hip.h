@@ -271,6 +271,20 @@ __global__ __launch_bounds__(256) void integrate_multi(MultiParams mp)
     multi_body<R, NT, FLAT>(mp.common, mp.frames, mp.n_frames, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
+// Experiment (variant 5): XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs, so
+// ids b and b + 8 share an L2; this remap hands each XCD one contiguous eighth of the slab instead of
+// every eighth workgroup.  Measured: no gain -- the only shared data is the 1.2 MB
+// depth frame, which every XCD's 4 MiB L2 holds whole either way; volume bytes are touched once.
+template <bool NT>
+__global__ __launch_bounds__(256) void integrate_multi_xcd(MultiParams mp)
+{
+    const unsigned nx = gridDim.x, ny = gridDim.y, n = nx * ny * gridDim.z;
+    unsigned id = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+    if (n % 8u == 0u) id = (id % 8u) * (n / 8u) + id / 8u;
+    const unsigned bx = id % nx, t = id / nx;
+    multi_body<1, NT, false>(mp.common, mp.frames, mp.n_frames, (int)bx, (int)(t % ny), (int)(t / ny));
+}
+
 // One frame, pose by value (no frame block in memory to stage): what a single tsdf_integrate* call
 // on a volume served by the flat mapping launches.
 template <bool NT, bool FLAT>

@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("dims", [(256, 42, 30), (200, 42, 30), (36, 20, 12)])   # row mapping, flat, flat + partial chunk
-@pytest.mark.parametrize("variant", [0, 4, 3])
+@pytest.mark.parametrize("variant", [0, 4, 3, 5])
 @pytest.mark.parametrize("n_frames", [1, 3, 4, 9])
 def test_fused_frames_equal_sequential_and_oracle(cuda, oracle, n_frames, variant, dims):
     vs = 2.0 / dims[0]                       # ragged row groups for R = 1 and R = 2
