@@ -478,6 +478,8 @@ int tsdf_create(const tsdf_config *cfg, tsdf_volume **out)
         return fail(TSDF_ERR_INVALID, "tsdf_create: voxel_size and trunc_margin must be > 0");
     if (cfg->dim_y > 65535 * 4 || (cfg->z_end - cfg->z_begin) > 65535)
         return fail(TSDF_ERR_INVALID, "tsdf_create: slab exceeds launch limits (dim_y <= 262140, slices <= 65535)");
+    if ((int64_t)cfg->dim_x * cfg->dim_y > ((int64_t)1 << 31) - 1024)
+        return fail(TSDF_ERR_INVALID, "tsdf_create: a slice may hold at most 2^31 voxels (dim_x * dim_y)");
 
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)

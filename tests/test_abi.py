@@ -83,6 +83,9 @@ def test_invalid_arguments_are_reported():
     cfg = capi.default_config()
     cfg.voxel_size = 0.0
     assert lib.tsdf_create(C.byref(cfg), C.byref(h)) == -1
+    cfg = capi.default_config()
+    cfg.dim_x, cfg.dim_y = 1 << 20, 1 << 12
+    assert lib.tsdf_create(C.byref(cfg), C.byref(h)) == -1 and b"slice" in lib.tsdf_last_error()
     assert lib.tsdf_create(None, C.byref(h)) == -1
     assert lib.tsdf_sync(None) == -1 and lib.tsdf_integrate(None, None, None) == -1
     assert lib.tsdf_destroy(None) == 0
