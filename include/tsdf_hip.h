@@ -214,6 +214,17 @@ int tsdf_save_ply(tsdf_volume *vol, const char *path, float weight_thresh);
 int tsdf_save_bin(tsdf_volume *vol, const char *path);
 
 /*
+ * Checkpoint / resume.  The reference only writes (ref: src/tsdf.cu:114-132) and nothing in it reads a
+ * .bin back.  tsdf_load_bin restores the TSDF array from a file in the reference's .bin format (its
+ * 8-float header must match the slab; weights are not in that format and are left untouched).
+ * tsdf_save_state / tsdf_load_state round-trip the whole slab (configuration, TSDF, weights) in this
+ * library's own format, so an interrupted fusion continues bit-exactly.
+ */
+int tsdf_load_bin(tsdf_volume *vol, const char *path);
+int tsdf_save_state(tsdf_volume *vol, const char *path);
+int tsdf_load_state(tsdf_volume *vol, const char *path);
+
+/*
  * Timing aid for benchmarks: queue n_frames integrations of one device-resident depth frame
  * with poses cam2world[k*16..] back to back on the handle's stream, bracketed by HIP events
  * on that stream; *elapsed_ms is the device time between the events.  Synchronous.

@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "tsdf_integrate_frames_device",
     "tsdf_sync", "tsdf_download", "tsdf_copy_slices", "tsdf_upload", "tsdf_refresh_summary", "tsdf_device_ptrs", "tsdf_slab_voxels",
     "tsdf_get_config", "tsdf_last_cam2base", "tsdf_set_stream", "tsdf_get_stream",
-    "tsdf_count_surface", "tsdf_extract_surface", "tsdf_extract_crossings", "tsdf_save_ply", "tsdf_save_bin",
+    "tsdf_count_surface", "tsdf_extract_surface", "tsdf_extract_crossings", "tsdf_save_ply", "tsdf_save_bin", "tsdf_load_bin", "tsdf_save_state", "tsdf_load_state",
     "tsdf_integrate_sequence_timed", "tsdf_probe_stream", "tsdf_selftest_fastdiv", "tsdf_selftest_round", "tsdf_set_kernel_variant", "tsdf_last_error",
     "tsdf_version", "tsdf_multiply_matrix", "tsdf_invert_matrix",
     "tsdf_labels_enable", "tsdf_compose_labels", "tsdf_integrate_labels_device", "tsdf_download_labels",
@@ -87,6 +87,9 @@ def load():
     L.tsdf_extract_crossings.argtypes = [vp, vp, vp, C.c_float, vp, C.c_int64, i64p]
     L.tsdf_save_ply.argtypes = [vp, C.c_char_p, C.c_float]
     L.tsdf_save_bin.argtypes = [vp, C.c_char_p]
+    L.tsdf_load_bin.argtypes = [vp, C.c_char_p]
+    L.tsdf_save_state.argtypes = [vp, C.c_char_p]
+    L.tsdf_load_state.argtypes = [vp, C.c_char_p]
     L.tsdf_integrate_sequence_timed.argtypes = [vp, vp, vp, C.c_int32, f32p]
     L.tsdf_probe_stream.argtypes = [vp, C.c_int32, C.c_int32, f32p]
     L.tsdf_selftest_fastdiv.argtypes = [C.c_int32, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), f32p]
@@ -388,6 +391,15 @@ class Volume:
 
     def save_bin(self, path):
         check(self.lib.tsdf_save_bin(self._h, os.fsencode(path)), "tsdf_save_bin")
+
+    def load_bin(self, path):
+        check(self.lib.tsdf_load_bin(self._h, os.fsencode(path)), "tsdf_load_bin")
+
+    def save_state(self, path):
+        check(self.lib.tsdf_save_state(self._h, os.fsencode(path)), "tsdf_save_state")
+
+    def load_state(self, path):
+        check(self.lib.tsdf_load_state(self._h, os.fsencode(path)), "tsdf_load_state")
 
 
 class Batch:

@@ -1255,4 +1255,62 @@ int tsdf_save_bin(tsdf_volume *v, const char *path)
     return TSDF_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// checkpoint / resume (the reference only ever writes: ref src/tsdf.cu:114-132; nothing reads a .bin back)
+// ---------------------------------------------------------------------------------------------
+int tsdf_load_bin(tsdf_volume *v, const char *path)
+{
+    if (!v || !path) return fail(TSDF_ERR_INVALID, "tsdf_load_bin: NULL argument");
+    FILE *fp = std::fopen(path, "rb");
+    if (!fp) return fail(TSDF_ERR_IO, "tsdf_load_bin: cannot open %s", path);
+    float hdr[8];
+    const tsdf_config &c = v->cfg;
+    const int nz = c.z_end - c.z_begin;
+    bool ok = std::fread(hdr, sizeof(float), 8, fp) == 8 && hdr[0] == (float)c.dim_x && hdr[1] == (float)c.dim_y &&
+              hdr[2] == (float)nz;
+    std::vector<float> host((size_t)(v->n_vox > 0 ? v->n_vox : 1));
+    ok = ok && std::fread(host.data(), sizeof(float), (size_t)v->n_vox, fp) == (size_t)v->n_vox;
+    std::fclose(fp);
+    if (!ok) return fail(TSDF_ERR_IO, "tsdf_load_bin: %s is not a %dx%dx%d TSDF dump", path, c.dim_x, c.dim_y, nz);
+    return tsdf_upload(v, host.data(), nullptr);   // weights are not in the reference's format
+}
+
+static const char kStateMagic[8] = {'T', 'S', 'D', 'F', 'H', 'I', 'P', '1'};
+
+int tsdf_save_state(tsdf_volume *v, const char *path)
+{
+    if (!v || !path) return fail(TSDF_ERR_INVALID, "tsdf_save_state: NULL argument");
+    std::vector<float> t((size_t)(v->n_vox > 0 ? v->n_vox : 1)), w(t.size());
+    int rc = tsdf_download(v, t.data(), w.data());
+    if (rc) return rc;
+    FILE *fp = std::fopen(path, "wb");
+    if (!fp) return fail(TSDF_ERR_IO, "tsdf_save_state: cannot open %s", path);
+    size_t ok = std::fwrite(kStateMagic, 1, 8, fp);
+    ok += std::fwrite(&v->cfg, sizeof(tsdf_config), 1, fp);
+    ok += std::fwrite(t.data(), sizeof(float), (size_t)v->n_vox, fp);
+    ok += std::fwrite(w.data(), sizeof(float), (size_t)v->n_vox, fp);
+    int bad = std::fclose(fp);
+    if (ok != 9 + 2 * (size_t)v->n_vox || bad) return fail(TSDF_ERR_IO, "tsdf_save_state: short write to %s", path);
+    return TSDF_OK;
+}
+
+int tsdf_load_state(tsdf_volume *v, const char *path)
+{
+    if (!v || !path) return fail(TSDF_ERR_INVALID, "tsdf_load_state: NULL argument");
+    FILE *fp = std::fopen(path, "rb");
+    if (!fp) return fail(TSDF_ERR_IO, "tsdf_load_state: cannot open %s", path);
+    char magic[8];
+    tsdf_config c;
+    bool ok = std::fread(magic, 1, 8, fp) == 8 && std::memcmp(magic, kStateMagic, 8) == 0 &&
+              std::fread(&c, sizeof c, 1, fp) == 1;
+    ok = ok && c.dim_x == v->cfg.dim_x && c.dim_y == v->cfg.dim_y && c.dim_z == v->cfg.dim_z &&
+         c.z_begin == v->cfg.z_begin && c.z_end == v->cfg.z_end;
+    std::vector<float> t((size_t)(v->n_vox > 0 ? v->n_vox : 1)), w(t.size());
+    ok = ok && std::fread(t.data(), sizeof(float), (size_t)v->n_vox, fp) == (size_t)v->n_vox &&
+         std::fread(w.data(), sizeof(float), (size_t)v->n_vox, fp) == (size_t)v->n_vox;
+    std::fclose(fp);
+    if (!ok) return fail(TSDF_ERR_IO, "tsdf_load_state: %s does not hold the state of this slab", path);
+    return tsdf_upload(v, t.data(), w.data());
+}
+
 }  // extern "C"

@@ -266,7 +266,7 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
 }
 
 template <int R, bool NT, bool FLAT>
-__global__ __launch_bounds__(256) void integrate_multi(MultiParams mp)
+__global__ __launch_bounds__(256, R == 2 ? 6 : 1) void integrate_multi(MultiParams mp)
 {
     multi_body<R, NT, FLAT>(mp.common, mp.frames, mp.n_frames, blockIdx.x, blockIdx.y, blockIdx.z);
 }

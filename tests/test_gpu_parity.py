@@ -394,3 +394,35 @@ def test_caller_owned_stream(cuda, oracle):
                          cfg.trunc_margin, ref_t, ref_w)
         t, w = vol.download()
     assert_parity(t, w, ref_t, ref_w)
+
+
+def test_checkpoint_resume(cuda, oracle, tmp_path):
+    """Interrupted fusion continues bit-exactly from tsdf_save_state / tsdf_load_state; a reference-format
+    .bin (TSDF only) written by the oracle's writer loads through tsdf_load_bin."""
+    dims, vs = (96, 64, 40), 0.01
+    origin = synth.surf_volume(96, vs, 0.6)
+    cfg = capi.make_config(dims, vs, origin)
+    scene = synth.SurfScene(dims, vs, origin)
+    frames = [(scene.pose(k, 8), scene.depth(scene.pose(k, 8), quantize=True)) for k in range(6)]
+    ref_t, ref_w = oracle.init_grid(dims)
+    with capi.Volume(cfg) as a:
+        for c2w, d in frames[:3]:
+            a.integrate(d, c2w)
+            oracle.integrate(cfg.cam_K, c2w, d, dims, origin, vs, cfg.trunc_margin, ref_t, ref_w)
+        a.save_state(str(tmp_path / "half.state"))
+        oracle.save_bin(str(tmp_path / "half.bin"), ref_t, dims, origin, vs, cfg.trunc_margin)
+    with capi.Volume(cfg) as b:
+        b.load_state(str(tmp_path / "half.state"))
+        for c2w, d in frames[3:]:
+            b.integrate(d, c2w)
+            oracle.integrate(cfg.cam_K, c2w, d, dims, origin, vs, cfg.trunc_margin, ref_t, ref_w)
+        t, w = b.download()
+        assert_parity(t, w, ref_t, ref_w)
+        b.load_bin(str(tmp_path / "half.bin"))          # reference format: TSDF only, weights stay
+        t2, w2 = b.download()
+        assert np.array_equal(w2, ref_w) and not np.array_equal(t2, t)
+        with pytest.raises(capi.TsdfError):
+            b.load_state(str(tmp_path / "half.bin"))     # wrong format is refused
+    with capi.Volume(capi.make_config((32, 32, 32), vs, origin)) as c:
+        with pytest.raises(capi.TsdfError):
+            c.load_state(str(tmp_path / "half.state"))   # wrong slab is refused
