@@ -59,6 +59,10 @@ class TSDFfusion
 		    ref: src/TSDFfusion.py.in:48-53).  Point cloud in the format of ref: src/tsdf.cu:185-212. */
 		void SavePointCloud(const std::string &file_name);
 
+		/** Triangle mesh of the fused surface to a binary .ply -- the native stand-in for the Python glue's
+		    SaveMesh (ref: src/TSDFfusion.py.in:48-53), by marching tetrahedra on the device. */
+		void SaveMesh(const std::string &file_name);
+
 		tsdf_volume *handle() const { return vol_; }
 
 	private:

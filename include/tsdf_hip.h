@@ -203,6 +203,18 @@ int tsdf_extract_crossings(tsdf_volume *vol, const float *halo_tsdf, const float
                            float *xyz_host, int64_t capacity, int64_t *count);
 
 /*
+ * Triangle mesh of the zero level set by marching tetrahedra, on the device, cubes in grid order,
+ * 9 floats (3 vertices) per triangle; a watertight, consistently wound triangle soup (edge vertices of
+ * neighbouring cubes are bit-identical).  Stands in for the reference's SaveMesh, which needs the absent
+ * tsdf-fusion-python (ref: src/TSDFfusion.py.in:48-53); rule in csrc/tsdf_extract.hip.h, checked against
+ * this project's CPU restatement only.  halo_* as for tsdf_extract_crossings.  tsdf_save_mesh_ply writes a
+ * binary .ply (vertex + face elements) of a whole-grid handle.
+ */
+int tsdf_extract_mesh(tsdf_volume *vol, const float *halo_tsdf, const float *halo_weight, float weight_thresh,
+                      float *triangles_host, int64_t capacity, int64_t *count);
+int tsdf_save_mesh_ply(tsdf_volume *vol, const char *path, float weight_thresh);
+
+/*
  * File writers, byte-compatible with the reference's destructor (ref: src/tsdf.cu:107-132,
  * 170-218).  For a slab handle the .bin header carries the slab's dims and a z-shifted
  * origin is NOT applied: callers that shard gather slabs in z order first (see

@@ -53,6 +53,8 @@ class Oracle:
         L.oracle_zero_crossings.restype = C.c_int64
         L.oracle_zero_crossings.argtypes = [_f32p, _f32p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
+        L.oracle_mesh_triangles.restype = C.c_int64
+        L.oracle_mesh_triangles.argtypes = L.oracle_zero_crossings.argtypes
         L.oracle_save_ply.restype = C.c_int
         L.oracle_save_ply.argtypes = [C.c_char_p, _f32p, _f32p, C.c_int, C.c_int, C.c_int,
                                       C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
@@ -136,6 +138,20 @@ class Oracle:
         xyz = np.empty((n, 3), np.float32)
         self.lib.oracle_zero_crossings(*args, xyz.ctypes.data)
         return xyz
+
+    def mesh_triangles(self, tsdf, weight, dims_xy, z_begin, z_end, voxel_size, origin, halo=None,
+                       weight_thresh=0.9):
+        """Marching-tetrahedra triangles of slab [z_begin, z_end): array [n, 3, 3] (project-defined rule)."""
+        ht = hw = None
+        if halo is not None:
+            ht_a, hw_a = _f32(halo[0]), _f32(halo[1])
+            ht, hw = ht_a.ctypes.data, hw_a.ctypes.data
+        args = (tsdf, weight, ht, hw, dims_xy[0], dims_xy[1], z_begin, z_end, voxel_size,
+                origin[0], origin[1], origin[2], weight_thresh)
+        n = self.lib.oracle_mesh_triangles(*args, None)
+        tri = np.empty((n, 3, 3), np.float32)
+        self.lib.oracle_mesh_triangles(*args, tri.ctypes.data)
+        return tri
 
     def save_ply(self, path, tsdf, weight, dims, voxel_size, origin, weight_thresh=0.9):
         dx, dy, dz = dims

@@ -254,6 +254,114 @@ int64_t oracle_zero_crossings(const float *tsdf, const float *weight, const floa
     return n;
 }
 
+/* ------------------------------------------------------------------------------------
+ * Triangle mesh by marching tetrahedra (NOT in the reference: its SaveMesh goes through the absent
+ * tsdf-fusion-python, ref: src/TSDFfusion.py.in:48-53).  Project-defined rule, restated here for the
+ * HIP kernels to be checked against -- parity unpinned by any reference output:
+ *   for every cube with base voxel v = (x, y, z) in grid order whose 8 corners c = dx + 2 dy + 4 dz all
+ *   have weight > thresh, for each of the 6 tetrahedra {0,1,3,7} {0,3,2,7} {0,2,6,7} {0,6,4,7} {0,4,5,7}
+ *   {0,5,1,7} in that order, with "inside" = tsdf < 0:
+ *     1 or 3 corners inside : one triangle on the three edges that leave the odd corner, taken in
+ *                             increasing corner position within the tetrahedron;
+ *     2 inside (A < B), C < D outside : two triangles (AC, AD, BD) and (AC, BD, BC);
+ *   an edge vertex between cube corners i < j is p_i + s (p_j - p_i), s = t_i / (t_i - t_j), per component
+ *   (sub, mul, add), p = origin + index * voxel_size (tsdf.cu:206-208): lower corner first, so that
+ *   cubes sharing an edge produce the same bits;
+ *   orientation: with n = (P1 - P0) x (P2 - P0) and q = the first inside corner of the tetrahedron in
+ *   its listed order, the triangle is emitted as (P0, P1, P2) if n . (P0 - p_q) >= 0, else (P0, P2, P1).
+ * The slab holds slices [z_begin, z_end); cubes of its top slice take their upper corners from halo_*
+ * (slice z_end) or are skipped when those are NULL.  tri: 9 floats per triangle, or NULL to count.
+ * ---------------------------------------------------------------------------------- */
+static const int kTet[6][4] = {{0, 1, 3, 7}, {0, 3, 2, 7}, {0, 2, 6, 7}, {0, 6, 4, 7}, {0, 4, 5, 7}, {0, 5, 1, 7}};
+
+static void mesh_edge(const float p[8][3], const float t[8], int a, int b, float out[3])
+{
+    const int i = a < b ? a : b, j = a < b ? b : a;
+    const float s = t[i] / (t[i] - t[j]);
+    for (int k = 0; k < 3; ++k) out[k] = p[i][k] + s * (p[j][k] - p[i][k]);
+}
+
+static int64_t mesh_emit(const float P0[3], const float P1[3], const float P2[3], const float q[3], float *tri, int64_t n)
+{
+    if (tri) {
+        const float e1[3] = {P1[0] - P0[0], P1[1] - P0[1], P1[2] - P0[2]};
+        const float e2[3] = {P2[0] - P0[0], P2[1] - P0[1], P2[2] - P0[2]};
+        const float nx = e1[1] * e2[2] - e1[2] * e2[1];
+        const float ny = e1[2] * e2[0] - e1[0] * e2[2];
+        const float nz = e1[0] * e2[1] - e1[1] * e2[0];
+        const float d = nx * (P0[0] - q[0]) + ny * (P0[1] - q[1]) + nz * (P0[2] - q[2]);
+        const float *A = P1, *B = P2;
+        if (!(d >= 0.0f)) { A = P2; B = P1; }
+        float *o = tri + 9 * n;
+        for (int k = 0; k < 3; ++k) { o[k] = P0[k]; o[3 + k] = A[k]; o[6 + k] = B[k]; }
+    }
+    return n + 1;
+}
+
+int64_t oracle_mesh_triangles(const float *tsdf, const float *weight, const float *halo_tsdf,
+                              const float *halo_weight, int dim_x, int dim_y, int z_begin, int z_end,
+                              float voxel_size, float origin_x, float origin_y, float origin_z,
+                              float weight_thresh, float *tri)
+{
+    int64_t n = 0;
+    const int64_t slice = (int64_t)dim_x * dim_y;
+    for (int z = z_begin; z < z_end; ++z) {
+        const int upper_in_slab = z + 1 < z_end;
+        if (!upper_in_slab && (!halo_tsdf || !halo_weight)) continue;
+        for (int y = 0; y + 1 < dim_y; ++y)
+            for (int x = 0; x + 1 < dim_x; ++x) {
+                float t[8], p[8][3];
+                int ok = 1;
+                for (int c = 0; c < 8; ++c) {
+                    const int cx = x + (c & 1), cy = y + ((c >> 1) & 1), cz = z + (c >> 2);
+                    float tv, wv;
+                    if (cz < z_end) {
+                        const int64_t i = (int64_t)(cz - z_begin) * slice + (int64_t)cy * dim_x + cx;
+                        tv = tsdf[i]; wv = weight[i];
+                    } else {
+                        tv = halo_tsdf[(int64_t)cy * dim_x + cx]; wv = halo_weight[(int64_t)cy * dim_x + cx];
+                    }
+                    if (!(wv > weight_thresh)) { ok = 0; break; }
+                    t[c] = tv;
+                    p[c][0] = origin_x + (float)cx * voxel_size;
+                    p[c][1] = origin_y + (float)cy * voxel_size;
+                    p[c][2] = origin_z + (float)cz * voxel_size;
+                }
+                if (!ok) continue;
+                for (int k = 0; k < 6; ++k) {
+                    const int *v = kTet[k];
+                    int in[4], cnt = 0;
+                    for (int a = 0; a < 4; ++a) { in[a] = t[v[a]] < 0.0f; cnt += in[a]; }
+                    if (cnt == 0 || cnt == 4) continue;
+                    int first_in = 0;
+                    while (!in[first_in]) ++first_in;
+                    const float *q = p[v[first_in]];
+                    float E[4][3];
+                    if (cnt == 1 || cnt == 3) {
+                        int odd = 0;
+                        for (int a = 0; a < 4; ++a) if (in[a] == (cnt == 1)) odd = a;
+                        int m = 0;
+                        for (int a = 0; a < 4; ++a) if (a != odd) mesh_edge(p, t, v[odd], v[a], E[m++]);
+                        n = mesh_emit(E[0], E[1], E[2], q, tri, n);
+                    } else {
+                        int A = -1, B = -1, C = -1, D = -1;
+                        for (int a = 0; a < 4; ++a) {
+                            if (in[a]) { if (A < 0) A = a; else B = a; }
+                            else { if (C < 0) C = a; else D = a; }
+                        }
+                        mesh_edge(p, t, v[A], v[C], E[0]);
+                        mesh_edge(p, t, v[A], v[D], E[1]);
+                        mesh_edge(p, t, v[B], v[D], E[2]);
+                        mesh_edge(p, t, v[B], v[C], E[3]);
+                        n = mesh_emit(E[0], E[1], E[2], q, tri, n);
+                        n = mesh_emit(E[0], E[2], E[3], q, tri, n);
+                    }
+                }
+            }
+    }
+    return n;
+}
+
 /* .ply writer: header text of tsdf.cu:185-192, then 3 floats per point (tsdf.cu:210-212). */
 int oracle_save_ply(const char *path, const float *tsdf, const float *weight,
                     int dim_x, int dim_y, int dim_z, float voxel_size,

@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "tsdf_integrate_frames_device",
     "tsdf_sync", "tsdf_download", "tsdf_copy_slices", "tsdf_upload", "tsdf_refresh_summary", "tsdf_device_ptrs", "tsdf_slab_voxels",
     "tsdf_get_config", "tsdf_last_cam2base", "tsdf_set_stream", "tsdf_get_stream",
-    "tsdf_count_surface", "tsdf_extract_surface", "tsdf_extract_crossings", "tsdf_save_ply", "tsdf_save_bin", "tsdf_load_bin", "tsdf_save_state", "tsdf_load_state",
+    "tsdf_count_surface", "tsdf_extract_surface", "tsdf_extract_crossings", "tsdf_extract_mesh", "tsdf_save_mesh_ply", "tsdf_save_ply", "tsdf_save_bin", "tsdf_load_bin", "tsdf_save_state", "tsdf_load_state",
     "tsdf_integrate_sequence_timed", "tsdf_probe_stream", "tsdf_selftest_fastdiv", "tsdf_selftest_round", "tsdf_set_kernel_variant", "tsdf_last_error",
     "tsdf_version", "tsdf_multiply_matrix", "tsdf_invert_matrix",
     "tsdf_labels_enable", "tsdf_compose_labels", "tsdf_integrate_labels_device", "tsdf_download_labels",
@@ -85,6 +85,8 @@ def load():
     L.tsdf_count_surface.argtypes = [vp, C.c_float, i64p]
     L.tsdf_extract_surface.argtypes = [vp, C.c_float, vp, C.c_int64, i64p]
     L.tsdf_extract_crossings.argtypes = [vp, vp, vp, C.c_float, vp, C.c_int64, i64p]
+    L.tsdf_extract_mesh.argtypes = [vp, vp, vp, C.c_float, vp, C.c_int64, i64p]
+    L.tsdf_save_mesh_ply.argtypes = [vp, C.c_char_p, C.c_float]
     L.tsdf_save_ply.argtypes = [vp, C.c_char_p, C.c_float]
     L.tsdf_save_bin.argtypes = [vp, C.c_char_p]
     L.tsdf_load_bin.argtypes = [vp, C.c_char_p]
@@ -385,6 +387,29 @@ class Volume:
                   "tsdf_extract_crossings")
             assert got.value == n.value
         return xyz
+
+    def extract_mesh(self, halo=None, weight_thresh=0.9):
+        """Marching-tetrahedra triangles of the slab, array [n, 3, 3]; halo as for extract_crossings."""
+        ht = hw = None
+        keep = None
+        if halo is not None:
+            if isinstance(halo[0], (int, np.integer)):
+                ht, hw = int(halo[0]), int(halo[1])
+            else:
+                keep = (_f32(halo[0]), _f32(halo[1]))
+                ht, hw = keep[0].ctypes.data, keep[1].ctypes.data
+        n = C.c_int64()
+        check(self.lib.tsdf_extract_mesh(self._h, ht, hw, weight_thresh, None, 0, C.byref(n)), "tsdf_extract_mesh")
+        tri = np.empty((n.value, 3, 3), np.float32)
+        if n.value:
+            got = C.c_int64()
+            check(self.lib.tsdf_extract_mesh(self._h, ht, hw, weight_thresh, tri.ctypes.data, n.value, C.byref(got)),
+                  "tsdf_extract_mesh")
+            assert got.value == n.value
+        return tri
+
+    def save_mesh_ply(self, path, weight_thresh=0.9):
+        check(self.lib.tsdf_save_mesh_ply(self._h, os.fsencode(path), weight_thresh), "tsdf_save_mesh_ply")
 
     def save_ply(self, path, weight_thresh=0.9):
         check(self.lib.tsdf_save_ply(self._h, os.fsencode(path), weight_thresh), "tsdf_save_ply")

@@ -1153,8 +1153,9 @@ int tsdf_extract_surface(tsdf_volume *v, float weight_thresh, float *xyz_host, i
 
 // Zero-crossing vertices.  halo_*: slice z_end from the upper neighbour (host or device memory) or NULL.
 static int crossing_pass(tsdf_volume *v, const float *halo_tsdf, const float *halo_weight, float weight_thresh,
-                         float *xyz_host, int64_t capacity, int64_t *count)
+                         float *xyz_host, int64_t capacity, int64_t *count, bool mesh = false)
 {
+    const size_t item_floats = mesh ? 9 : 3;   // triangle = 3 vertices, crossing = 1 vertex
     int rc = bind_device(v);
     if (rc) return rc;
     *count = 0;
@@ -1186,7 +1187,8 @@ static int crossing_pass(tsdf_volume *v, const float *halo_tsdf, const float *ha
     }
     g.n = n; g.dim_x = c.dim_x; g.dim_y = c.dim_y; g.nz = c.z_end - c.z_begin; g.z_begin = c.z_begin;
     g.thr = weight_thresh; g.ox = c.origin[0]; g.oy = c.origin[1]; g.oz = c.origin[2]; g.vs = c.voxel_size;
-    hipLaunchKernelGGL(tsdfx::crossing_count, dim3((unsigned)n_chunks), dim3(256), 0, v->stream, g, d_counts);
+    if (mesh) hipLaunchKernelGGL(tsdfx::mesh_count, dim3((unsigned)n_chunks), dim3(256), 0, v->stream, g, d_counts);
+    else hipLaunchKernelGGL(tsdfx::crossing_count, dim3((unsigned)n_chunks), dim3(256), 0, v->stream, g, d_counts);
     hipLaunchKernelGGL(tsdfx::scan_counts, dim3(1), dim3(1024), 0, v->stream, d_counts, n_chunks, d_offsets, d_total);
     HIP_TRY(hipGetLastError());
     int64_t total = 0;
@@ -1196,11 +1198,12 @@ static int crossing_pass(tsdf_volume *v, const float *halo_tsdf, const float *ha
     if (!xyz_host || capacity <= 0 || total == 0) return TSDF_OK;
     const int64_t n_out = total < capacity ? total : capacity;
     float *d_xyz = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_xyz, (size_t)total * 3 * sizeof(float)));
-    hipLaunchKernelGGL(tsdfx::crossing_emit, dim3((unsigned)n_chunks), dim3(256), 0, v->stream, g, d_offsets, d_xyz);
+    HIP_TRY(hipMalloc((void **)&d_xyz, (size_t)total * item_floats * sizeof(float)));
+    if (mesh) hipLaunchKernelGGL(tsdfx::mesh_emit_kernel, dim3((unsigned)n_chunks), dim3(256), 0, v->stream, g, d_offsets, d_xyz);
+    else hipLaunchKernelGGL(tsdfx::crossing_emit, dim3((unsigned)n_chunks), dim3(256), 0, v->stream, g, d_offsets, d_xyz);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess)
-        e = hipMemcpyAsync(xyz_host, d_xyz, (size_t)n_out * 3 * sizeof(float), hipMemcpyDeviceToHost, v->stream);
+        e = hipMemcpyAsync(xyz_host, d_xyz, (size_t)n_out * item_floats * sizeof(float), hipMemcpyDeviceToHost, v->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(v->stream);
     (void)hipFree(d_xyz);
     if (e != hipSuccess) return fail(TSDF_ERR_HIP, "zero crossings: %s", hipGetErrorString(e));
@@ -1212,6 +1215,42 @@ int tsdf_extract_crossings(tsdf_volume *v, const float *halo_tsdf, const float *
 {
     if (!v || !count) return fail(TSDF_ERR_INVALID, "tsdf_extract_crossings: NULL argument");
     return crossing_pass(v, halo_tsdf, halo_weight, weight_thresh, xyz_host, capacity, count);
+}
+
+int tsdf_extract_mesh(tsdf_volume *v, const float *halo_tsdf, const float *halo_weight, float weight_thresh,
+                      float *triangles_host, int64_t capacity, int64_t *count)
+{
+    if (!v || !count) return fail(TSDF_ERR_INVALID, "tsdf_extract_mesh: NULL argument");
+    return crossing_pass(v, halo_tsdf, halo_weight, weight_thresh, triangles_host, capacity, count, true);
+}
+
+int tsdf_save_mesh_ply(tsdf_volume *v, const char *path, float weight_thresh)
+{
+    if (!v || !path) return fail(TSDF_ERR_INVALID, "tsdf_save_mesh_ply: NULL argument");
+    int64_t n = 0;
+    int rc = crossing_pass(v, nullptr, nullptr, weight_thresh, nullptr, 0, &n, true);
+    if (rc) return rc;
+    std::vector<float> tri((size_t)(n > 0 ? n : 1) * 9);
+    if (n > 0) {
+        rc = crossing_pass(v, nullptr, nullptr, weight_thresh, tri.data(), n, &n, true);
+        if (rc) return rc;
+    }
+    FILE *fp = std::fopen(path, "wb");
+    if (!fp) return fail(TSDF_ERR_IO, "tsdf_save_mesh_ply: cannot open %s", path);
+    std::fprintf(fp, "ply\nformat binary_little_endian 1.0\nelement vertex %lld\n", (long long)(3 * n));
+    std::fprintf(fp, "property float x\nproperty float y\nproperty float z\n");
+    std::fprintf(fp, "element face %lld\nproperty list uchar int vertex_indices\nend_header\n", (long long)n);
+    size_t ok = std::fwrite(tri.data(), sizeof(float), (size_t)n * 9, fp);
+    std::vector<unsigned char> faces((size_t)(n > 0 ? n : 1) * 13);
+    for (int64_t f = 0; f < n; ++f) {
+        unsigned char *rec = faces.data() + 13 * f;
+        rec[0] = 3;
+        for (int k = 0; k < 3; ++k) { const int32_t idx = (int32_t)(3 * f + k); std::memcpy(rec + 1 + 4 * k, &idx, 4); }
+    }
+    ok += std::fwrite(faces.data(), 13, (size_t)n, fp);
+    int bad = std::fclose(fp);
+    if (ok != (size_t)n * 9 + (size_t)n || bad) return fail(TSDF_ERR_IO, "tsdf_save_mesh_ply: short write to %s", path);
+    return TSDF_OK;
 }
 
 int tsdf_save_ply(tsdf_volume *v, const char *path, float weight_thresh)

@@ -167,3 +167,10 @@ void TSDFfusion::SavePointCloud(const std::string &file_name)
 	if (tsdf_save_ply(vol_, file_name.c_str(), 0.9f) != TSDF_OK)
 		throw std::runtime_error(std::string("TSDFfusion::SavePointCloud: ") + tsdf_last_error());
 }
+
+void TSDFfusion::SaveMesh(const std::string &file_name)
+{
+	std::cout << "Saving to " << file_name << " ... " << std::endl;  // ref: src/TSDFfusion.py.in:51
+	if (tsdf_save_mesh_ply(vol_, file_name.c_str(), 0.9f) != TSDF_OK)
+		throw std::runtime_error(std::string("TSDFfusion::SaveMesh: ") + tsdf_last_error());
+}

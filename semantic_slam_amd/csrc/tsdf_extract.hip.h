@@ -221,4 +221,176 @@ __global__ __launch_bounds__(256) void crossing_emit(CrossingGrid g, const int64
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Triangle mesh by marching tetrahedra.  Not in the reference (its SaveMesh needs the absent Python
+// package, ref: src/TSDFfusion.py.in:48-53); the rule is this project's own and is checked bit for bit
+// against its CPU restatement in the test suite (tests/test_gpu_mesh.py):
+//   every cube with base voxel (x, y, z) whose 8 corners c = dx + 2 dy + 4 dz all have weight > thr is cut
+//   into the 6 tetrahedra around the diagonal 0-7; inside = tsdf < 0; 1 or 3 corners inside -> one
+//   triangle, 2 -> two; an edge vertex between cube corners i < j is p_i + s (p_j - p_i) with
+//   s = t_i / (t_i - t_j) (lower corner first: cubes sharing an edge produce the same bits, so the soup is
+//   a watertight 2-manifold); winding so that the normal points away from the inside corner.
+// Cubes of a slab's top slice take their upper corners from the halo slice (RCCL z halo), or are skipped.
+// Output: 9 floats per triangle, cubes in grid order -- same three-pass compaction as above, ranks inside
+// a wavefront by a shuffle scan because a cube emits 0..12 triangles.
+// ------------------------------------------------------------------------------------------
+__constant__ int kTet[6][4] = {{0, 1, 3, 7}, {0, 3, 2, 7}, {0, 2, 6, 7}, {0, 6, 4, 7}, {0, 4, 5, 7}, {0, 5, 1, 7}};
+
+// Loads the 8 corner values of the cube based at slab-local linear index i; false if it is not a cube
+// of this slab (border voxel, missing halo, unobserved corner).
+__device__ __forceinline__ bool load_cube(const CrossingGrid &g, int64_t i, float t[8], int &x, int &y, int &lz)
+{
+    if (i >= g.n) return false;
+    const int64_t slice = (int64_t)g.dim_x * g.dim_y;
+    lz = (int)(i / slice);
+    const int rem = (int)(i - (int64_t)lz * slice);
+    y = rem / g.dim_x;
+    x = rem - y * g.dim_x;
+    if (x + 1 >= g.dim_x || y + 1 >= g.dim_y) return false;
+    const bool upper_in_slab = lz + 1 < g.nz;
+    if (!upper_in_slab && g.halo_tsdf == nullptr) return false;
+    bool ok = true;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int64_t off = (int64_t)(c & 1) + (int64_t)((c >> 1) & 1) * g.dim_x;
+        float tv, wv;
+        if (!(c >> 2) || upper_in_slab) {
+            const int64_t j = i + off + (int64_t)(c >> 2) * slice;
+            tv = g.tsdf[j]; wv = g.weight[j];
+        } else {
+            tv = g.halo_tsdf[rem + off]; wv = g.halo_weight[rem + off];
+        }
+        ok = ok && (wv > g.thr);
+        t[c] = tv;
+    }
+    return ok;
+}
+
+__device__ __forceinline__ uint32_t cube_triangle_count(const float t[8])
+{
+    uint32_t n = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        int cnt = 0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) cnt += t[kTet[k][a]] < 0.0f ? 1 : 0;
+        n += (cnt == 1 || cnt == 3) ? 1u : (cnt == 2 ? 2u : 0u);
+    }
+    return n;
+}
+
+__device__ __forceinline__ void mesh_edge(const float p[8][3], const float t[8], int a, int b, float out[3])
+{
+    const int i = a < b ? a : b, j = a < b ? b : a;
+    const float s = t[i] / (t[i] - t[j]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out[k] = p[i][k] + s * (p[j][k] - p[i][k]);
+}
+
+__device__ __forceinline__ void mesh_emit(const float P0[3], const float P1[3], const float P2[3], const float q[3],
+                                          float *o)
+{
+    const float e1[3] = {P1[0] - P0[0], P1[1] - P0[1], P1[2] - P0[2]};
+    const float e2[3] = {P2[0] - P0[0], P2[1] - P0[1], P2[2] - P0[2]};
+    const float nx = e1[1] * e2[2] - e1[2] * e2[1];
+    const float ny = e1[2] * e2[0] - e1[0] * e2[2];
+    const float nz = e1[0] * e2[1] - e1[1] * e2[0];
+    const float d = nx * (P0[0] - q[0]) + ny * (P0[1] - q[1]) + nz * (P0[2] - q[2]);
+    const bool keep = d >= 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        o[k] = P0[k];
+        o[3 + k] = keep ? P1[k] : P2[k];
+        o[6 + k] = keep ? P2[k] : P1[k];
+    }
+}
+
+__global__ __launch_bounds__(256) void mesh_count(CrossingGrid g, uint32_t *counts)
+{
+    __shared__ uint32_t wave_sum[4];
+    const int64_t base = (int64_t)blockIdx.x * kChunk;
+    uint32_t c = 0;
+    for (int k = 0; k < kPerThread; ++k) {
+        float t[8];
+        int x, y, lz;
+        if (load_cube(g, base + k * 256 + threadIdx.x, t, x, y, lz)) c += cube_triangle_count(t);
+    }
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+    if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+}
+
+__global__ __launch_bounds__(256) void mesh_emit_kernel(CrossingGrid g, const int64_t *offsets, float *tri)
+{
+    __shared__ uint32_t cnt[kPerThread * 4];  // [k][wave] in output order
+    const int64_t base = (int64_t)blockIdx.x * kChunk;
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    for (int k = 0; k < kPerThread; ++k) {
+        float t[8];
+        int x, y, lz;
+        uint32_t c = load_cube(g, base + k * 256 + threadIdx.x, t, x, y, lz) ? cube_triangle_count(t) : 0u;
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+        if (lane == 0) cnt[k * 4 + wave] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int j = 0; j < kPerThread * 4; ++j) { uint32_t c = cnt[j]; cnt[j] = run; run += c; }
+    }
+    __syncthreads();
+    const int64_t chunk_off = offsets[blockIdx.x];
+    for (int k = 0; k < kPerThread; ++k) {
+        float t[8];
+        int x, y, lz;
+        const bool ok = load_cube(g, base + k * 256 + threadIdx.x, t, x, y, lz);
+        const uint32_t mine = ok ? cube_triangle_count(t) : 0u;
+        uint32_t incl = mine;                       // inclusive scan over the wavefront
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off);
+            if (lane >= off) incl += up;
+        }
+        if (mine == 0u) continue;
+        int64_t pos = chunk_off + cnt[k * 4 + wave] + (incl - mine);
+        float p[8][3];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            p[c][0] = g.ox + (float)(x + (c & 1)) * g.vs;
+            p[c][1] = g.oy + (float)(y + ((c >> 1) & 1)) * g.vs;
+            p[c][2] = g.oz + (float)(g.z_begin + lz + (c >> 2)) * g.vs;
+        }
+        for (int kt = 0; kt < 6; ++kt) {
+            int v[4], in[4], n_in = 0;
+            for (int a = 0; a < 4; ++a) { v[a] = kTet[kt][a]; in[a] = t[v[a]] < 0.0f ? 1 : 0; n_in += in[a]; }
+            if (n_in == 0 || n_in == 4) continue;
+            int first_in = 0;
+            while (!in[first_in]) ++first_in;
+            const float *q = p[v[first_in]];
+            float E[4][3];
+            if (n_in == 1 || n_in == 3) {
+                int odd = 0;
+                for (int a = 0; a < 4; ++a) if (in[a] == (n_in == 1 ? 1 : 0)) odd = a;
+                int m = 0;
+                for (int a = 0; a < 4; ++a) if (a != odd) mesh_edge(p, t, v[odd], v[a], E[m++]);
+                mesh_emit(E[0], E[1], E[2], q, tri + 9 * pos);
+                ++pos;
+            } else {
+                int A = -1, B = -1, C = -1, D = -1;
+                for (int a = 0; a < 4; ++a) {
+                    if (in[a]) { if (A < 0) A = a; else B = a; }
+                    else { if (C < 0) C = a; else D = a; }
+                }
+                mesh_edge(p, t, v[A], v[C], E[0]);
+                mesh_edge(p, t, v[A], v[D], E[1]);
+                mesh_edge(p, t, v[B], v[D], E[2]);
+                mesh_edge(p, t, v[B], v[C], E[3]);
+                mesh_emit(E[0], E[1], E[2], q, tri + 9 * pos);
+                mesh_emit(E[0], E[2], E[3], q, tri + 9 * (pos + 1));
+                pos += 2;
+            }
+        }
+    }
+}
+
 }  // namespace tsdfx

@@ -153,6 +153,19 @@ class ShardedVolume:
             return None
         return np.concatenate([g.reshape(-1, 3) for g in gathered]).astype(np.float32)
 
+    def gather_mesh(self, weight_thresh=0.9, dst=0):
+        """Marching-tetrahedra triangles of the whole grid in grid order on rank dst: halo exchange, per-slab
+        extraction on each device, concatenation in z order (identical to the unsharded mesh)."""
+        ht, hw = self.halo_exchange()
+        tri = self.slab.extract_mesh(None if ht is None else (ht, hw), weight_thresh)
+        if self.world == 1:
+            return tri
+        gathered = [None] * self.world if self.rank == dst else None
+        self.dist.gather_object(tri, gathered, dst=self._global_rank(dst), group=self.group)
+        if self.rank != dst:
+            return None
+        return np.concatenate([g.reshape(-1, 3, 3) for g in gathered]).astype(np.float32)
+
     def gather_surface(self, weight_thresh=0.9, dst=0):
         """Surface points of the whole grid in grid order on rank dst (ref rule: src/tsdf.cu:179).
         Per-voxel rule: each rank compacts its own slab on its GPU, lists are concatenated in z order."""

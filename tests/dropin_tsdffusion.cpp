@@ -26,6 +26,7 @@ int main(int argc, char **argv)
 	}
 	std::fclose(fp);
 	tsdf->SavePointCloud(argv[2]);
+	if (argc > 3) tsdf->SaveMesh(argv[3]);                       // ref: SaveMesh of src/TSDFfusion.py.in:48-53
 	delete tsdf;
 	return 0;
 }

@@ -94,13 +94,18 @@ def test_tsdffusion_native_backend(cuda, oracle, tmp_path):
             f.write(pose.astype(np.float32).tobytes())
             f.write(d.astype(np.float32).tobytes())
     out = tmp_path / "cloud.ply"
-    subprocess.check_call([exe, str(inp), str(out)], cwd=str(tmp_path))
+    mesh = tmp_path / "mesh.ply"
+    subprocess.check_call([exe, str(inp), str(out), str(mesh)], cwd=str(tmp_path))
     t, w = oracle.init_grid(dims)
     for pose, d in frames:
         oracle.integrate(synth.TUM_K, pose, d, dims, origin, vs, float(np.float32(vs) * np.float32(5)), t, w)
     assert w.sum() > 10000
     oracle.save_ply(str(tmp_path / "want.ply"), t, w, dims, vs, origin)
     assert out.read_bytes() == (tmp_path / "want.ply").read_bytes()
+    tri = oracle.mesh_triangles(t, w, dims[:2], 0, dims[2], vs, origin)
+    raw = mesh.read_bytes()
+    body = raw[raw.index(b"end_header\n") + len(b"end_header\n"):]
+    assert len(tri) > 1000 and body[:36 * len(tri)] == tri.tobytes()
 
 
 def test_python_mirror_of_class_tsdf(cuda, oracle, tmp_path):

@@ -67,3 +67,20 @@ def test_label_fusion_rule(oracle):
     far = np.full((48, 64), 3.0, f32)
     li, si = np.full((48, 64), 9, np.uint16), np.full((48, 64), 0.9, f32)
     assert oracle.integrate_labels(K, pose, far, li, si, dims, origin, vs, 0.05, lab, fp, bp) == 0
+
+
+def test_mesh_rule_known_answers(oracle):
+    """One cube with one corner inside: three tetrahedra touch corner 0 ... the surface is a closed fan."""
+    t = np.ones(8, f32)
+    t[0] = -1.0                                   # corner (0,0,0) inside, all others outside at +1: s = 0.5 on every edge
+    w = np.ones(8, f32)
+    tri = oracle.mesh_triangles(t, w, (2, 2), 0, 2, 1.0, np.zeros(3, f32))
+    assert tri.shape == (6, 3, 3)                 # all six tetrahedra contain corner 0
+    assert np.allclose(np.abs(tri).max(), 0.5) and np.all((tri == 0) | (tri == 0.5))
+    n = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+    assert np.all(np.einsum("ij,ij->i", n, tri.mean(1)) > 0)        # wound away from the inside corner
+    # an unobserved corner removes the cube; no upper slice and no halo removes it too
+    w2 = w.copy(); w2[5] = 0.0
+    assert len(oracle.mesh_triangles(t, w2, (2, 2), 0, 2, 1.0, np.zeros(3, f32))) == 0
+    assert len(oracle.mesh_triangles(t[:4], w[:4], (2, 2), 0, 1, 1.0, np.zeros(3, f32))) == 0
+    assert np.array_equal(oracle.mesh_triangles(t[:4], w[:4], (2, 2), 0, 1, 1.0, np.zeros(3, f32), halo=(t[4:], w[4:])), tri)

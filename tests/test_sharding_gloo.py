@@ -46,6 +46,9 @@ class OracleSlab:
     def extract_crossings(self, halo=None, thr=0.9):
         return self.o.zero_crossings(self.t, self.w, DIMS[:2], self.zb, self.ze, VS, self.origin, halo, thr)
 
+    def extract_mesh(self, halo=None, thr=0.9):
+        return self.o.mesh_triangles(self.t, self.w, DIMS[:2], self.zb, self.ze, VS, self.origin, halo, thr)
+
     def extract_surface(self, thr=0.9):
         dims = (DIMS[0], DIMS[1], self.ze - self.zb)
         pts = self.o.surface_points(self.t, self.w, dims, VS, self.origin, thr)
@@ -74,7 +77,8 @@ def worker(rank, world, port, q):
         t, w = vol.gather(dst=0)
         pts = vol.gather_surface(dst=0)
         xing = vol.gather_crossings(dst=0)
-        q.put((rank, ht, hw, t, w, pts, xing))
+        mesh = vol.gather_mesh(dst=0)
+        q.put((rank, ht, hw, t, w, pts, xing, mesh))
     finally:
         dist.destroy_process_group()
 
@@ -106,10 +110,12 @@ def test_sharded_equals_whole(world):
     whole = OracleSlab(0, DIMS[2])
     for pose, depth in frames():
         whole.integrate(depth, pose)
-    _, _, t, w, pts, xing = out[0]
+    _, _, t, w, pts, xing, mesh = out[0]
     assert whole.w.sum() > 0
     assert np.array_equal(w, whole.w) and np.array_equal(t.view(np.uint32), whole.t.view(np.uint32))
     assert np.array_equal(pts.view(np.uint32), whole.extract_surface().view(np.uint32))
+    want_m = whole.extract_mesh(None)
+    assert len(want_m) > 100 and np.array_equal(mesh.view(np.uint32), want_m.view(np.uint32))
     want_x = whole.extract_crossings(None)
     assert len(want_x) > 100 and np.array_equal(xing.view(np.uint32), want_x.view(np.uint32))
     s = DIMS[0] * DIMS[1]
