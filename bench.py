@@ -32,6 +32,10 @@ def parse():
     ap.add_argument("--grid", type=int, default=512, help="grid edge in voxels (512 or 1024)")
     ap.add_argument("--workload", default="sfull", choices=["sfull", "ssurf"])
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (see DESIGN.md)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = every rank integrates a slab as large as the whole N = 1 grid (the global grid "
+                         "grows with N: 512^3 -> 512x512x1024 -> 512x1024x1024 -> 1024^3 at N = 1, 2, 4, 8, same physical "
+                         "extent, finer voxels); strong = the N = 1 grid cut into N slabs")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="single-GPU rehearsal of one rank of an N-GPU job: integrate only rank 0's z-slab of N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -112,23 +116,41 @@ def main():
 
     D = args.grid
     vs = {512: 0.005, 1024: 0.002}.get(D, 2.56 / D)
-    dims = (D, D, D)
+    dims = [D, D, D]
+    part_world = args.emulate_world if (args.emulate_world > 1 and world == 1) else world
+    if args.scaling == "weak" and part_world > 1:
+        # per-rank work fixed: grow the grid with N inside the same physical box (z, then y, then x doubled in
+        # turn, voxels halved whenever z is doubled); a rank count that is not a power of two just gets N x the slices
+        k, n = 0, part_world
+        while n % 2 == 0:
+            n //= 2
+            k += 1
+        if n == 1:
+            for i in range(k):
+                dims[2 - i % 3] *= 2
+            vs = vs / 2 ** ((k + 2) // 3)
+        else:
+            dims[2] *= part_world
+            vs = vs / part_world
+    dims = tuple(dims)
     if args.workload == "sfull":
-        origin = synth.sfull_volume(D, vs)
+        origin = synth.sfull_volume(dims, vs)
         depth = synth.sfull_depth()
         n_pose = 64
         poses = np.stack([synth.sfull_pose(k) for k in range(n_pose)])
     else:
-        origin = synth.surf_volume(D, vs, 1.0)
+        origin = synth.surf_volume(max(dims), vs, 1.0)
         scene = synth.SurfScene(dims, vs, origin)
         n_pose = 64
         poses = np.stack([scene.pose(k, n_pose) for k in range(n_pose)])
         depth = scene.depth(poses[0], quantize=True)  # one resident frame, orbiting camera
 
     # z-slab of this rank (ref layout is z-major, so a slab is one contiguous range)
-    zb, ze = rank * D // world, (rank + 1) * D // world
+    Dz = dims[2]
+    zb, ze = rank * Dz // world, (rank + 1) * Dz // world
     if args.emulate_world > 1 and world == 1:
-        zb, ze = 0, D // args.emulate_world
+        zb, ze = 0, Dz // args.emulate_world
+    n_global = dims[0] * dims[1] * dims[2]
     cfg = capi.make_config(dims, vs, origin, z_begin=zb, z_end=ze, device=local_rank)
     vol = capi.Volume(cfg)
     vol.set_kernel_variant(args.variant)
@@ -210,6 +232,8 @@ def main():
         try:
             rec = json.load(open(tpath))
             key = f"{args.workload}_{D}_slab{ze - zb}" + ("" if args.variant == 0 else f"_v{args.variant}")
+            if dims != (D, D, D):
+                key += "_" + "x".join(str(d) for d in dims)
             if key in rec:
                 traffic = rec[key]["hbm_bytes_per_launch"]
         except Exception:
@@ -217,19 +241,20 @@ def main():
 
     line = {
         "metric": f"Mvoxels/sec integrated, {D}^3 grid @ 640x480 depth; achieved HBM GB/s %peak",
-        "value": round((D ** 3 if args.emulate_world <= 1 else n_slab) * args.steps / wall / 1e6, 1),
+        "value": round((n_global if args.emulate_world <= 1 else n_slab) * args.steps / wall / 1e6, 1),
         "unit": "Mvoxels/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(wall / args.steps * 1e3, 5),
         "higher_is_better": True,
-        "scaling": "strong",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"{args.workload} {D}^3 @ {vs * 1000:g} mm, 640x480 depth resident in HBM, "
+        "config": {"workload": f"{args.workload} {dims[0]}x{dims[1]}x{dims[2]} @ {vs * 1000:g} mm, 640x480 depth resident in HBM, "
                                f"{'every voxel updated every frame' if args.workload == 'sfull' else 'sphere+wall orbit'}",
-                   "grid": [D, D, D], "voxel_size_m": vs, "image": [H, W],
-                   "partition": f"{world} z-slab(s) of {ze - zb} slices, one per GPU",
+                   "grid": list(dims), "voxel_size_m": vs, "image": [H, W],
+                   "partition": f"{world} z-slab(s) of {ze - zb} slices ({n_slab} voxels), one per GPU"
+                                + (f"; {args.scaling} scaling from the {D}^3 grid of N = 1" if world > 1 else ""),
                    "kernel_variant": args.variant},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -270,7 +295,7 @@ def main():
             "kernel": "tsdfk::integrate_tile<R=1,NT> (variant 17): 16 B per updated voxel, nothing elided",
             "kernel_ms": round(ms_s, 5), "bytes_per_launch": int(b_s),
             "achieved": round(b_s / (ms_s * 1e-3) / 1e9, 1), "frac": round(b_s / (ms_s * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "value": round(D ** 3 / ms_s / 1e3, 1), "unit": "GB/s (value: Mvoxels/s)"}
+            "value": round(n_global / ms_s / 1e3, 1), "unit": "GB/s (value: Mvoxels/s)"}
         vol.set_kernel_variant(0)
         vol.reset()
     if world == 1 and args.emulate_world <= 1:
@@ -284,7 +309,7 @@ def main():
         vol.sync()
         dt = time.perf_counter() - t1
         line["host_depth_path"] = {"ms_per_step": round(dt / n_host * 1e3, 5),
-                                   "value": round(D ** 3 * n_host / dt / 1e6, 1), "unit": "Mvoxels/s",
+                                   "value": round(n_global * n_host / dt / 1e6, 1), "unit": "Mvoxels/s",
                                    "note": "tsdf_integrate with a host depth pointer: memcpy to pinned staging + "
                                            "H2D copy + kernel per frame, Python ctypes call overhead included"}
     if not args.no_cpu_baseline and world == 1 and args.emulate_world <= 1:

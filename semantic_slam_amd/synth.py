@@ -55,13 +55,16 @@ def make_pose(R, t):
 # S-full
 # --------------------------------------------------------------------------------------
 def sfull_volume(dim, voxel_size):
-    """origin (base-camera frame) of a dim^3 volume centred on the optical axis at z0 = 3.2 m."""
-    half = dim * voxel_size / 2.0
-    # in-image bound from tsdf.cu:41-43: y/z < (479.5-247.6)/539.2 = 0.4301 binds first
-    assert SFULL_Z0 * 0.4301 > half * (math.cos(0.04) + math.sin(0.04)) + 1e-3, \
+    """origin (base-camera frame) of a volume centred on the optical axis at z0 = 3.2 m that stays wholly
+    inside the frustum for every pose of sfull_pose.  dim: edge in voxels, or (dim_x, dim_y, dim_z)."""
+    dx, dy, dz = (dim, dim, dim) if np.isscalar(dim) else dim
+    hx, hy = dx * voxel_size / 2.0, dy * voxel_size / 2.0
+    wobble = math.cos(0.04) + math.sin(0.04)
+    # in-image bounds from tsdf.cu:41-43: |x/z| < 0.5965, y/z < (479.5-247.6)/539.2 = 0.4301 (binds first)
+    assert SFULL_Z0 * 0.4301 > max(hx, hy) * wobble + 1e-3, \
         "volume does not fit the frustum at z0: not a full-coverage workload"
-    assert SFULL_Z0 + dim * voxel_size < SFULL_DEPTH, "far face beyond the constant depth"
-    return np.array([-half, -half, SFULL_Z0], dtype=np.float32)
+    assert SFULL_Z0 + dz * voxel_size < SFULL_DEPTH, "far face beyond the constant depth"
+    return np.array([-hx, -hy, SFULL_Z0], dtype=np.float32)
 
 
 def sfull_depth(h=IM_H, w=IM_W):
