@@ -5,10 +5,12 @@
 
 One "step" = one Integrate of one 640x480 depth frame into the whole grid.  At N = 1 the
 workload is BASELINE.json configs[1]: 512^3 @ 5 mm, synthetic depth + pose stream (S-full,
-SURVEY.md section 8d: every voxel updated every frame, so algorithmic bytes = 16 B x voxels).  For
-N > 1 the SAME grid is cut into N z-slabs, one per rank (strong scaling, no data-path
-collective: voxels are independent); launch with torch.distributed.run as the driver does.
-The depth frame is resident in HBM before the timed region.  Rank 0 prints one JSON line.
+SURVEY.md section 8d: every voxel updated every frame).  For N > 1 every rank owns one z-slab and
+there is no data-path collective (voxels are independent); by default the scaling is WEAK: each rank's
+slab holds as many voxels as the whole N = 1 grid and the global grid grows inside the same physical
+box (1024^3 @ 2.5 mm at N = 8); --scaling strong cuts the 512^3 grid itself.  Launch with
+torch.distributed.run as the driver does.  The depth frame is resident in HBM before the timed
+region.  Rank 0 prints one JSON line.
 """
 import argparse
 import json
