@@ -253,9 +253,12 @@ int tsdf_probe_stream(tsdf_volume *vol, int32_t non_temporal, int32_t n_iters, f
 /*
  * Device self-test of the kernel's shared-reciprocal division against the compiler's IEEE
  * division on n_samples pseudo-random operand pairs in the range the kernel uses it for
- * (DESIGN.md section 4).  *mismatches must come back 0; first_bad = {n, d, got, want} otherwise.
+ * (DESIGN.md section 4).  A quotient may differ from the IEEE one only below 2^-42 and only if the
+ * pixel coordinate fl(fx*q + cx) it feeds is unchanged for the given fx, cx (any |fx| < 2^14 the
+ * kernel's fast path admits).  *mismatches must come back 0; first_bad = {n, d, got, want} otherwise.
  */
-int tsdf_selftest_fastdiv(int32_t device, uint64_t seed, uint64_t n_samples, uint64_t *mismatches, float first_bad[4]);
+int tsdf_selftest_fastdiv(int32_t device, uint64_t seed, uint64_t n_samples, float fx, float cx,
+                          uint64_t *mismatches, float first_bad[4]);
 
 /*
  * Exhaustive device self-test of the kernel's one-instruction pixel rounding (v_cvt_rpi_i32_f32)

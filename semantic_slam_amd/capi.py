@@ -94,7 +94,7 @@ def load():
     L.tsdf_load_state.argtypes = [vp, C.c_char_p]
     L.tsdf_integrate_sequence_timed.argtypes = [vp, vp, vp, C.c_int32, f32p]
     L.tsdf_probe_stream.argtypes = [vp, C.c_int32, C.c_int32, f32p]
-    L.tsdf_selftest_fastdiv.argtypes = [C.c_int32, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), f32p]
+    L.tsdf_selftest_fastdiv.argtypes = [C.c_int32, C.c_uint64, C.c_uint64, C.c_float, C.c_float, C.POINTER(C.c_uint64), f32p]
     L.tsdf_selftest_round.argtypes = [C.c_int32, C.POINTER(C.c_uint64), f32p]
     L.tsdf_set_kernel_variant.argtypes = [vp, C.c_int32]
     L.tsdf_last_error.restype = C.c_char_p
@@ -170,11 +170,11 @@ def invert_matrix(m):
     return bool(ok), out
 
 
-def selftest_fastdiv(n_samples, seed=1, device=0):
+def selftest_fastdiv(n_samples, seed=1, device=0, fx=535.4, cx=320.1):
     """Returns (mismatches, first_bad[4]) of the device division self-test."""
     cnt = C.c_uint64()
     bad = (C.c_float * 4)()
-    check(load().tsdf_selftest_fastdiv(device, seed, n_samples, C.byref(cnt), bad), "tsdf_selftest_fastdiv")
+    check(load().tsdf_selftest_fastdiv(device, seed, n_samples, fx, cx, C.byref(cnt), bad), "tsdf_selftest_fastdiv")
     return cnt.value, list(bad)
 
 

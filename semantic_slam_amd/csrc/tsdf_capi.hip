@@ -777,7 +777,8 @@ int tsdf_set_kernel_variant(tsdf_volume *v, int32_t variant)
     return TSDF_OK;
 }
 
-int tsdf_selftest_fastdiv(int32_t device, uint64_t seed, uint64_t n_samples, uint64_t *mismatches, float first_bad[4])
+int tsdf_selftest_fastdiv(int32_t device, uint64_t seed, uint64_t n_samples, float fx, float cx,
+                          uint64_t *mismatches, float first_bad[4])
 {
     if (!mismatches || !first_bad) return fail(TSDF_ERR_INVALID, "tsdf_selftest_fastdiv: NULL argument");
     HIP_TRY(hipSetDevice(device));
@@ -787,7 +788,7 @@ int tsdf_selftest_fastdiv(int32_t device, uint64_t seed, uint64_t n_samples, uin
     HIP_TRY(hipMalloc((void **)&d_bad, 4 * sizeof(float)));
     HIP_TRY(hipMemset(d_cnt, 0, sizeof *d_cnt));
     HIP_TRY(hipMemset(d_bad, 0, 4 * sizeof(float)));
-    hipLaunchKernelGGL(tsdfk::selftest_fastdiv, dim3(256 * 8), dim3(256), 0, 0, seed, n_samples, 535.4f, 320.1f, d_cnt, d_bad);
+    hipLaunchKernelGGL(tsdfk::selftest_fastdiv, dim3(256 * 8), dim3(256), 0, 0, seed, n_samples, fx, cx, d_cnt, d_bad);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipDeviceSynchronize();
     unsigned long long cnt = 0;

@@ -604,7 +604,8 @@ __global__ __launch_bounds__(256) void integrate_tile(IntegrateParams p)
 // counter hash, denominators in [2^-60, 2^60], numerators up to 2^60 in magnitude (plus exact
 // zeros and structured mantissas).  A sample passes when the quotients are bit-identical, or --
 // for quotients below 2^-42, where the unscaled sequence may lose the last bit of a denormal
-// residual -- when the pixel coordinate fl(f*q + c) the kernel derives from it is identical.
+// residual -- when the pixel the kernel derives from it (rounding of fl(f*q + c) and the u > -0.5 test)
+// is identical.
 __device__ __forceinline__ uint32_t hash32(uint64_t x)
 {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
@@ -636,8 +637,13 @@ __global__ __launch_bounds__(256) void selftest_fastdiv(uint64_t seed, uint64_t 
         const float r0 = n0 / d, r1 = n1 / d;
         bool bad0 = __float_as_uint(q.x) != __float_as_uint(r0);
         bool bad1 = __float_as_uint(q.y) != __float_as_uint(r1);
-        if (bad0 && fabsf(r0) < 2.2737368e-13f) bad0 = __float_as_uint(fx * q.x + cx) != __float_as_uint(fx * r0 + cx);
-        if (bad1 && fabsf(r1) < 2.2737368e-13f) bad1 = __float_as_uint(fx * q.y + cx) != __float_as_uint(fx * r1 + cx);
+        // what the kernel derives from a quotient: the pixel (round_half_up_i32) and the `u > -0.5` test
+        auto same_pixel = [&](float qa, float qb) {
+            const float ua = fx * qa + cx, ub = fx * qb + cx;
+            return round_half_up_i32(ua) == round_half_up_i32(ub) && (ua > -0.5f) == (ub > -0.5f);
+        };
+        if (bad0 && fabsf(r0) < 2.2737368e-13f) bad0 = !same_pixel(q.x, r0);
+        if (bad1 && fabsf(r1) < 2.2737368e-13f) bad1 = !same_pixel(q.y, r1);
         if (bad0 || bad1) {
             if (atomicAdd(mismatch, 1ull) == 0ull) {
                 first_bad[0] = bad0 ? n0 : n1; first_bad[1] = d; first_bad[2] = bad0 ? q.x : q.y;

@@ -15,6 +15,14 @@ def test_fast_division_is_ieee_exact(cuda, seed):
     assert bad == 0, f"{bad} mismatches, first: n={first[0]!r} d={first[1]!r} got={first[2]!r} want={first[3]!r}"
 
 
+@pytest.mark.parametrize("fx,cx", [(16383.0, 0.0), (16383.0, 0.5), (-16383.0, -0.49999997), (1e-3, 1e-30), (16383.0, 1e-20)])
+def test_tiny_quotients_cannot_move_a_pixel_for_any_admitted_intrinsics(cuda, fx, cx):
+    """Below 2^-42 the unscaled sequence may lose the last bit of a denormal residual; the pixel coordinate
+    fl(fx*q + cx) must not notice, for the largest focal length the fast path admits and awkward centres."""
+    bad, first = capi.selftest_fastdiv(1 << 28, seed=77, fx=fx, cx=cx)
+    assert bad == 0, f"{bad} mismatches, first: n={first[0]!r} d={first[1]!r} got={first[2]!r} want={first[3]!r}"
+
+
 def test_one_instruction_rounding_equals_roundf_everywhere(cuda):
     """v_cvt_rpi_i32_f32 == (int)roundf for EVERY fp32 value in (-0.5, 2^24] (exhaustive, ~2.3e9 values)."""
     bad, first = capi.selftest_round()
