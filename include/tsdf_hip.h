@@ -292,6 +292,15 @@ int tsdf_integrate_labels_device(tsdf_volume *vol, const float *depth_dev, const
 int tsdf_download_labels(tsdf_volume *vol, uint16_t *label_host, float *fp_host, float *bp_host);
 
 /*
+ * Grid origin of a new object volume from its first (masked) depth frame, on the device: the per-axis
+ * minimum over pixels with depth > 0 of the back-projected point, starting from 1000 -- what
+ * Object::Object computes on the host before it constructs its TSDF (ref: src/Object.cpp:37-49, with the
+ * instance mask of ref: src/Engine.cpp:192-193; mask_dev may be NULL).  Bit-identical to that loop.
+ */
+int tsdf_object_origin(int32_t device, const float *depth_dev, const uint8_t *mask_dev, int32_t im_height,
+                       int32_t im_width, const float cam_K[9], float origin_out[3]);
+
+/*
  * Batched per-object fusion: the reference keeps one small TSDF per object instance and feeds
  * each of them depth * (its instance mask) for every keyframe (ref: src/Engine.cpp:172-233,
  * src/Object.cpp:67,143-166).  A batch owns n volumes (own grid, origin and base pose each; same

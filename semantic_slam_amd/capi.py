@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "tsdf_integrate_sequence_timed", "tsdf_probe_stream", "tsdf_selftest_fastdiv", "tsdf_selftest_round", "tsdf_set_kernel_variant", "tsdf_last_error",
     "tsdf_version", "tsdf_multiply_matrix", "tsdf_invert_matrix",
     "tsdf_labels_enable", "tsdf_compose_labels", "tsdf_integrate_labels_device", "tsdf_download_labels",
-    "tsdf_batch_create", "tsdf_batch_destroy", "tsdf_batch_size", "tsdf_batch_volume",
+    "tsdf_object_origin", "tsdf_batch_create", "tsdf_batch_destroy", "tsdf_batch_size", "tsdf_batch_volume",
     "tsdf_batch_integrate_device", "tsdf_batch_sync",
 ]
 
@@ -106,6 +106,7 @@ def load():
     L.tsdf_compose_labels.argtypes = [vp, vp, vp, vp, C.c_int32, vp, vp]
     L.tsdf_integrate_labels_device.argtypes = [vp, vp, vp, vp, vp]
     L.tsdf_download_labels.argtypes = [vp, vp, vp, vp]
+    L.tsdf_object_origin.argtypes = [C.c_int32, vp, vp, C.c_int32, C.c_int32, vp, vp]
     L.tsdf_batch_create.argtypes = [C.POINTER(TsdfConfig), C.c_int32, C.POINTER(vp)]
     L.tsdf_batch_destroy.argtypes = [vp]
     L.tsdf_batch_size.argtypes = [vp]
@@ -176,6 +177,14 @@ def selftest_fastdiv(n_samples, seed=1, device=0, fx=535.4, cx=320.1):
     bad = (C.c_float * 4)()
     check(load().tsdf_selftest_fastdiv(device, seed, n_samples, fx, cx, C.byref(cnt), bad), "tsdf_selftest_fastdiv")
     return cnt.value, list(bad)
+
+
+def object_origin(depth_ptr, mask_ptr, h, w, K, device=0):
+    """Origin of a new object volume from its first masked depth frame (ref: src/Object.cpp:37-49), on the device."""
+    k = _f32(K, 9)
+    out = np.empty(3, np.float32)
+    check(load().tsdf_object_origin(device, depth_ptr, mask_ptr, h, w, k.ctypes.data, out.ctypes.data), "tsdf_object_origin")
+    return out
 
 
 def selftest_round(device=0):

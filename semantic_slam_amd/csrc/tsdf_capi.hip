@@ -801,6 +801,28 @@ int tsdf_selftest_fastdiv(int32_t device, uint64_t seed, uint64_t n_samples, flo
     return TSDF_OK;
 }
 
+int tsdf_object_origin(int32_t device, const float *depth_dev, const uint8_t *mask_dev, int32_t im_height,
+                       int32_t im_width, const float cam_K[9], float origin_out[3])
+{
+    if (!depth_dev || !cam_K || !origin_out || im_height <= 0 || im_width <= 0)
+        return fail(TSDF_ERR_INVALID, "tsdf_object_origin: bad argument");
+    HIP_TRY(hipSetDevice(device));
+    float *d_out = nullptr;
+    const float init[3] = {1000.0f, 1000.0f, 1000.0f};   // ref: src/Object.cpp:37
+    HIP_TRY(hipMalloc((void **)&d_out, sizeof init));
+    hipError_t e = hipMemcpy(d_out, init, sizeof init, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        const int n = im_height * im_width;
+        hipLaunchKernelGGL(tsdfk::object_origin, dim3(std::min((n + 255) / 256, 1024)), dim3(256), 0, 0, depth_dev, mask_dev,
+                           im_height, im_width, cam_K[0], cam_K[4], cam_K[2], cam_K[5], d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(origin_out, d_out, sizeof init, hipMemcpyDeviceToHost);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(TSDF_ERR_HIP, "tsdf_object_origin: %s", hipGetErrorString(e));
+    return TSDF_OK;
+}
+
 int tsdf_selftest_round(int32_t device, uint64_t *mismatches, float first_bad[4])
 {
     if (!mismatches || !first_bad) return fail(TSDF_ERR_INVALID, "tsdf_selftest_round: NULL argument");

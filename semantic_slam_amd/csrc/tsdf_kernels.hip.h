@@ -728,6 +728,39 @@ __global__ __launch_bounds__(256) void depth_u16_to_f32(const uint16_t *raw, flo
     }
 }
 
+// Grid origin of a new object volume: per-axis minimum, over the pixels with (masked) depth > 0, of the
+// back-projected point x = (c - cx) * z * (1/fx), y = (r - cy) * z * (1/fy), z -- starting from 1000
+// (ref: Object::Object, src/Object.cpp:37-49; the mask is the instance mask of src/Engine.cpp:192-193).
+// A minimum does not depend on the order of evaluation, so the device result equals the host loop's bits.
+// out[3] must be initialised to 1000.0f; positive floats order like their bit patterns, negative ones
+// in reverse, hence the two atomics.
+__device__ __forceinline__ void atomic_min_float(float *addr, float v)
+{
+    if (v >= 0.0f) atomicMin(reinterpret_cast<int *>(addr), __float_as_int(v));
+    else atomicMax(reinterpret_cast<unsigned int *>(addr), __float_as_uint(v));
+}
+
+__global__ __launch_bounds__(256) void object_origin(const float *depth, const uint8_t *mask, int H, int W, float fx,
+                                                     float fy, float cx, float cy, float *out)
+{
+    float mx = 1000.0f, my = 1000.0f, mz = 1000.0f;
+    const float ifx = 1.0f / fx, ify = 1.0f / fy;
+    const int n = H * W;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float z = depth[i];
+        if (mask != nullptr) z = z * (mask[i] >= 128 ? 1.0f : 0.0f);
+        if (z <= 0.0f) continue;
+        const int r = i / W, c = i - r * W;
+        const float x = ((float)c - cx) * z * ifx;
+        const float y = ((float)r - cy) * z * ify;
+        mx = fminf(mx, x); my = fminf(my, y); mz = fminf(mz, z);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        mx = fminf(mx, __shfl_down(mx, off)); my = fminf(my, __shfl_down(my, off)); mz = fminf(mz, __shfl_down(mz, off));
+    }
+    if ((threadIdx.x & 63) == 0) { atomic_min_float(out + 0, mx); atomic_min_float(out + 1, my); atomic_min_float(out + 2, mz); }
+}
+
 // TSDF = 1, weight = 0 (ref: src/tsdf.cu:79-81) written at bandwidth on the device.
 __global__ __launch_bounds__(256) void fill_grid(float *tsdf, float *weight, size_t n)
 {

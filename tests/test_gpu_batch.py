@@ -62,3 +62,21 @@ def test_batch_rejects_bad_members():
     c = capi.make_config((64, 64, 64), 0.01, [0, 0, 1], im_height=240, im_width=320)
     with pytest.raises(capi.TsdfError, match="image size"):
         capi.Batch([a, c])
+
+
+def test_object_origin_on_device_equals_the_host_loop(cuda, oracle):
+    """ref: src/Object.cpp:37-49 -- per-axis minimum of the back-projected masked depth, bit for bit."""
+    rng = np.random.default_rng(5)
+    scene = synth.SurfScene((200, 200, 200), 0.004, np.array([-0.4, -0.4, 0.7], np.float32))
+    depth = scene.depth(scene.pose(3, 16), quantize=True)
+    depth[rng.integers(0, 480, 500), rng.integers(0, 640, 500)] = -1.0
+    mask = np.zeros((480, 640), np.uint8)
+    mask[120:400, 200:520] = 255
+    d_dev, m_dev = cuda.from_numpy(depth).cuda(), cuda.from_numpy(mask).cuda()
+    got = capi.object_origin(d_dev.data_ptr(), m_dev.data_ptr(), 480, 640, synth.TUM_K)
+    want = oracle.object_origin(oracle.mask_depth(depth, mask), synth.TUM_K)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)) and want[0] < 0 < want[2] < 1000
+    got = capi.object_origin(d_dev.data_ptr(), None, 480, 640, synth.TUM_K)
+    assert np.array_equal(got.view(np.uint32), oracle.object_origin(depth, synth.TUM_K).view(np.uint32))
+    zero = cuda.zeros((480, 640), dtype=cuda.float32, device="cuda")
+    assert np.array_equal(capi.object_origin(zero.data_ptr(), None, 480, 640, synth.TUM_K), [1000, 1000, 1000])
