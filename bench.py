@@ -260,7 +260,7 @@ def main():
                    "kernel_variant": args.variant},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "kernel": "tsdfk::integrate_multi<1,true,false>" if fused else
+                     "kernel": "tsdfk::integrate_multi_inline<1,true,false>" if fused else
                                ("tsdfk::integrate_tile<2,true,true,false,true,false,true>" if v == 3 else f"variant {v}"),
                      "frames_per_launch": fpl, "launches": launches,
                      "kernel_ms": round(kernel_ms, 5),

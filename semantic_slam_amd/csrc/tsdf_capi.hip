@@ -179,6 +179,7 @@ tsdfk::IntegrateParams make_params(const tsdf_volume *v, const float *depth_dev,
 //   3        as 0 but one launch per frame even for sequences
 //   4        as 0 with integrate_multi<R=2> (experiment; the default fuses with R=1)
 //   5        as 0 with an XCD-aware workgroup order (experiment)
+//   6        as 0 with the frame blocks staged in device memory instead of the kernarg (A/B)
 //   1        scalar kernel integrate_rows<1> (any dim_x)
 //   2        first version integrate_rows<4> (one row per wavefront, no elision)
 //   16 + c   experiments: c = (rsel << 2) | (elide << 1) | nt, R = 1, 2, 4 for rsel = 0, 1, 2
@@ -232,7 +233,7 @@ int launch_integrate(tsdf_volume *v, const float *depth_dev, const uint8_t *mask
     if (nz == 0) return TSDF_OK;  // empty slab: nothing to do
     std::memcpy(v->last_cam2base, c2b, sizeof v->last_cam2base);
     int variant = v->variant;
-    if (variant == 0 || variant == 3 || variant == 4 || variant == 5) variant = kDefaultTile;
+    if (variant == 0 || (variant >= 3 && variant <= 6)) variant = kDefaultTile;
     if (c.dim_x % 4 != 0) variant = 1;  // rows are not 16-byte aligned: scalar kernel
     if (v->flat && variant != 1 && variant != 2) {
         // rows that are not a multiple of 256 voxels: the flat mapping (every lane busy, summary kept)
@@ -345,6 +346,26 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
         HIP_TRY(hipGetLastError());
         return TSDF_OK;
     }
+    std::memcpy(v->last_cam2base, c2b + 16 * (n - 1), sizeof v->last_cam2base);
+    v->flags_known_zero = false;   // integrate_multi maintains the summary
+    dim3 block(64, 4, 1);
+    if (v->variant != 4 && v->variant != 5 && v->variant != 6) {   // frame blocks in the kernarg: nothing staged
+        tsdfk::MultiParamsInline mi;
+        mi.common = make_params(v, depth_dev[0], nullptr, c2b, 4);
+        mi.n_frames = n;
+        for (int f = 0; f < n; ++f) fill_pose(mi.frames[f], f);
+        for (int f = n; f < tsdfk::kMaxFramesPerLaunch; ++f) mi.frames[f] = mi.frames[0];
+        if (v->flat) {
+            dim3 grid((v->chunks_per_slice + 3) / 4, 1, nz);
+            hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, true>), grid, block, 0, v->stream, mi);
+        } else {
+            dim3 grid((mi.common.xgroups + 63) / 64, (c.dim_y + 3) / 4, nz);
+            hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false>), grid, block, 0, v->stream, mi);
+        }
+        HIP_TRY(hipGetLastError());
+        return TSDF_OK;
+    }
+    // experiments (variants 4, 5, 6): frame blocks staged in device memory
     const int s = v->frames_next;
     v->frames_next = (s + 1) % kStageSlots;
     const size_t bytes = tsdfk::kMaxFramesPerLaunch * sizeof(tsdfk::FramePose);
@@ -360,9 +381,6 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
     mp.n_frames = n;
     for (int f = 0; f < n; ++f) fill_pose(v->h_frames[s][f], f);
     HIP_TRY(hipMemcpyAsync(v->d_frames[s], v->h_frames[s], n * sizeof(tsdfk::FramePose), hipMemcpyHostToDevice, v->stream));
-    std::memcpy(v->last_cam2base, c2b + 16 * (n - 1), sizeof v->last_cam2base);
-    v->flags_known_zero = false;   // integrate_multi maintains the summary
-    dim3 block(64, 4, 1);
     if (v->flat) {
         dim3 grid((v->chunks_per_slice + 3) / 4, 1, nz);
         hipLaunchKernelGGL((tsdfk::integrate_multi<1, true, true>), grid, block, 0, v->stream, mp);
@@ -372,7 +390,7 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
     } else if (v->variant == 4) {   // experiment: two rows per lane
         dim3 grid((mp.common.xgroups + 63) / 64, (c.dim_y + 7) / 8, nz);
         hipLaunchKernelGGL((tsdfk::integrate_multi<2, true, false>), grid, block, 0, v->stream, mp);
-    } else {
+    } else {                        // variant 6: the default kernel with staged frame blocks (A/B of the kernarg path)
         dim3 grid((mp.common.xgroups + 63) / 64, (c.dim_y + 3) / 4, nz);
         hipLaunchKernelGGL((tsdfk::integrate_multi<1, true, false>), grid, block, 0, v->stream, mp);
     }
@@ -386,7 +404,7 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
 int integrate_frames(tsdf_volume *v, const float *const *depth_dev, const uint8_t *const *masks_dev,
                      const float *cam2world, int n_frames)
 {
-    const bool fuse = (v->variant == 0 || v->variant == 4 || v->variant == 5) && v->cfg.dim_x % 4 == 0;
+    const bool fuse = (v->variant == 0 || (v->variant >= 4 && v->variant <= 6)) && v->cfg.dim_x % 4 == 0;
     int rc = TSDF_OK;
     for (int k = 0; k < n_frames && rc == TSDF_OK;) {
         const int n = fuse ? std::min(tsdfk::kMaxFramesPerLaunch, n_frames - k) : 1;
@@ -771,7 +789,7 @@ int tsdf_set_kernel_variant(tsdf_volume *v, int32_t variant)
     if (!v) return fail(TSDF_ERR_INVALID, "tsdf_set_kernel_variant: NULL handle");
     const int c = (variant - 32) & 15;
     const bool sum_ok = (variant >= 32 && variant < 112 && c < 12 && ((c >> 1) & 1)) || variant == 115 || variant == 119;
-    if (!(variant >= 0 && variant <= 5) && !(variant >= 16 && variant < 28) && !sum_ok)
+    if (!(variant >= 0 && variant <= 6) && !(variant >= 16 && variant < 28) && !sum_ok)
         return fail(TSDF_ERR_INVALID, "tsdf_set_kernel_variant: unknown variant %d", variant);
     v->variant = variant;
     return TSDF_OK;

@@ -33,6 +33,16 @@ struct MultiParams {
     int n_frames;             // in the kernarg would be copied to registers and selected per frame)
 };
 
+// The same with the frame blocks inside the kernarg itself: nothing to stage in device memory before the
+// launch (a 4 us copy on the stream per launch -- 1 % of a 512^3 pass, 8 % of a 200^3 one).  The kernel
+// reads them through the kernarg segment pointer with the loop's wave-uniform index (scalar loads),
+// not through the by-value parameter, which the compiler would copy to registers frame by frame.
+struct MultiParamsInline {
+    IntegrateParams common;
+    FramePose frames[kMaxFramesPerLaunch];
+    int n_frames;
+};
+
 // FLAT: the lane's quad comes from the linear view of the slice (IntegrateParams::quads_per_slice):
 // wavefront = 64 consecutive quads in memory order, whatever dim_x % 4 == 0 is -- rows shorter than or
 // not a multiple of 256 voxels no longer leave lanes idle (200-voxel rows: 50 of 64 lanes in the row
@@ -269,6 +279,17 @@ template <int R, bool NT, bool FLAT>
 __global__ __launch_bounds__(256, R == 2 ? 6 : 1) void integrate_multi(MultiParams mp)
 {
     multi_body<R, NT, FLAT>(mp.common, mp.frames, mp.n_frames, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+template <int R, bool NT, bool FLAT>
+__global__ __launch_bounds__(256, R == 2 ? 6 : 1) void integrate_multi_inline(MultiParamsInline mp)
+{
+    // the single by-value parameter starts the kernarg segment (offset 0)
+    typedef const char __attribute__((address_space(4))) *kernarg_ptr;
+    kernarg_ptr base = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    typedef const FramePose __attribute__((address_space(4))) *frames_ptr;
+    frames_ptr frames = (frames_ptr)(base + offsetof(MultiParamsInline, frames));
+    multi_body<R, NT, FLAT>(mp.common, (const FramePose *)frames, mp.n_frames, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Experiment (variant 5): XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs, so
