@@ -166,7 +166,8 @@ tsdfk::IntegrateParams make_params(const tsdf_volume *v, const float *depth_dev,
         p.cz_margin = ok ? (float)std::fmax(1e-5 * bz, 1e-17) : 3.0e38f;
         ok = ok && std::fabs((double)p.fx) < 16384.0 && std::fabs((double)p.fy) < 16384.0 &&
              std::fabs((double)p.cx) < 1048576.0 && std::fabs((double)p.cy) < 1048576.0 &&
-             (int64_t)c.im_width * c.im_height <= (1 << 24);   // pixel index exact in fp32
+             (int64_t)c.im_width * c.im_height <= (1 << 24) &&   // pixel index exact in fp32
+             c.im_width < (1 << 24) && c.im_height < (1 << 24);   // and its factors fit the 24-bit multiply
         p.fast_ok = ok ? 1 : 0;
     }
     return p;

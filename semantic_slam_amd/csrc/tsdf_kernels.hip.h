@@ -270,6 +270,21 @@ __device__ __forceinline__ void vol_store(float *p, float4 v)
 // Coarse frustum gate for the speculative loads: true unless the patch's four corners
 // (x0|x1, y0|y1 at slice gz) are all behind the camera or all beyond the same image edge by
 // more than one pixel.  Lanes 0..3 each project one corner; approximate arithmetic is fine.
+// depth[px] through a 32-bit byte offset from the wave-uniform base: the load takes the base from SGPRs
+// and the offset from one VGPR (global_load_dword v, v_off, s[base]) instead of a 64-bit address built
+// per voxel.  px < 2^30 pixels (tsdf_create refuses larger images), so px * 4 does not wrap.
+__device__ __forceinline__ float gather_f32(const float *__restrict__ base, uint32_t px)
+{
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + (px << 2));
+}
+
+// Pixel index iv * W + iu on the fast path: both factors are below 2^24 there (host: fast_ok), so the
+// full-rate 24-bit multiply-add gives the same integer as the quarter-rate 32-bit one.
+__device__ __forceinline__ int pixel_index24(int iv, int W, int iu)
+{
+    return (int)(__umul24((unsigned)iv, (unsigned)W) + (unsigned)iu);
+}
+
 __device__ __forceinline__ bool patch_may_be_visible(const IntegrateParams &p, int x0, int x1, int y0,
                                                      int y1, int gz)
 {
@@ -428,6 +443,7 @@ __device__ __forceinline__ void integrate_tile_body(const IntegrateParams &p, co
         //    only round to a negative pixel, which ref: src/tsdf.cu:43 rejects -- so the lower bound
         //    is tested on u itself, the upper one on the integer (unsigned compare).
         const v2f F = {p.fx, p.fy}, C = {p.cx, p.cy};
+        const bool front = cmin > p.cz_margin;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const bool row_ok = gy0 + r < p.dim_y;
@@ -441,10 +457,11 @@ __device__ __forceinline__ void integrate_tile_body(const IntegrateParams &p, co
                 const float cz = pcz[r][j];
                 const v2f uv = F * fast_div2(n, cz) + C;           // ref: :41-42 before rounding
                 const int iu = round_half_up_i32(uv.x), iv = round_half_up_i32(uv.y);
-                const bool ok = row_ok && cz > 0.0f && uv.x > -0.5f && uv.y > -0.5f &&
-                                (unsigned)iu < (unsigned)p.W && (unsigned)iv < (unsigned)p.H;
+                // cz > 0 for the whole patch or for none of it (corner test above): `front`
+                const bool ok = row_ok & front & (uv.x > -0.5f) & (uv.y > -0.5f) &
+                                ((unsigned)iu < (unsigned)p.W) & ((unsigned)iv < (unsigned)p.H);
                 geo[r][j] = ok;
-                pixel[r][j] = ok ? iv * p.W + iu : 0;
+                pixel[r][j] = ok ? pixel_index24(iv, p.W, iu) : 0;
                 if constexpr (LDSD) { pix_u[r][j] = ok ? iu : 0; pix_v[r][j] = ok ? iv : 0; }
             }
         }
@@ -483,9 +500,9 @@ __device__ __forceinline__ void integrate_tile_body(const IntegrateParams &p, co
             if constexpr (LDSD) {
                 const uint32_t du = (uint32_t)(pix_u[r][j] - tu0), dv = (uint32_t)(pix_v[r][j] - tv0);
                 if (du < (uint32_t)tw && dv < (uint32_t)th) d = lds_depth[dv * tw + du];
-                else d = p.depth[px];   // outside the staged tile (or no tile): the exact pixel from memory
+                else d = gather_f32(p.depth, px);   // outside the staged tile (or no tile): the exact pixel from memory
             } else {
-                d = p.depth[px];
+                d = gather_f32(p.depth, px);
             }
             if (MASKED == 1 || (MASKED == 2 && p.mask != nullptr))
                 d = d * (p.mask[px] >= 128 ? 1.0f : 0.0f);  // ref: src/Engine.cpp:192-193

@@ -110,8 +110,21 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
         const float dz = bz - q.tz;
         const float x2 = q.rx2 * dz, y2 = q.ry2 * dz, z2 = q.rz2 * dz;
         float pcz[R][4], dval[R][4];
-        bool geo[R][4];
-        int pixel[R][4];
+        // The depth sample of a voxel, or 0 when its projection is rejected (ref: src/tsdf.cu:39-43): 0 fails
+        // the depth test below exactly as the reference's `continue` does, so no separate validity flag
+        // has to survive until then.  The load is skipped (exec-masked), not redirected.
+        // The mask byte is fetched with it and applied after all loads of the frame have been issued.
+        int mval[R][4];
+        auto fetch = [&](const int r, const int j, const bool ok, const uint32_t px) {
+            float d = 0.0f;
+            int m = 255;
+            if (ok) {
+                d = gather_f32(q.depth, px);
+                if (q.mask != nullptr) m = q.mask[px];
+            }
+            dval[r][j] = d;
+            mval[r][j] = m;
+        };
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const float z1 = q.rz1 * (byv[r] - q.ty);
@@ -123,6 +136,7 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
         const float cmax = fmaxf(fmaxf(pcz[0][0], pcz[0][3]), fmaxf(pcz[R - 1][0], pcz[R - 1][3]));
         const bool unsafe = !(cmin > q.cz_margin) & !(cmax < -q.cz_margin);
         if (q.fast_ok != 0 && __ballot(unsafe) == 0ull) {
+            const bool front = cmin > q.cz_margin;   // the sign of cz over the whole patch (corner test)
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const bool row_ok = gy0 + r < p.dim_y;
@@ -136,10 +150,9 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
                     const float cz = pcz[r][j];
                     const v2f uv = F * fast_div2(n, cz) + C;
                     const int iu = round_half_up_i32(uv.x), iv = round_half_up_i32(uv.y);
-                    const bool ok = row_ok && cz > 0.0f && uv.x > -0.5f && uv.y > -0.5f &&
-                                    (unsigned)iu < (unsigned)p.W && (unsigned)iv < (unsigned)p.H;
-                    geo[r][j] = ok;
-                    pixel[r][j] = ok ? iv * p.W + iu : 0;
+                    const bool ok = row_ok & front & (uv.x > -0.5f) & (uv.y > -0.5f) &
+                                    ((unsigned)iu < (unsigned)p.W) & ((unsigned)iv < (unsigned)p.H);
+                    fetch(r, j, ok, (uint32_t)pixel_index24(iv, p.W, iu));
                 }
             }
         } else {
@@ -157,20 +170,16 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
                     const float pv = roundf(p.fy * (cy / cz) + p.cy);
                     const bool ok = row_ok && !(cz <= 0.0f) && pu >= 0.0f && pu < (float)p.W && pv >= 0.0f &&
                                     pv < (float)p.H;
-                    geo[r][j] = ok;
-                    pixel[r][j] = ok ? (int)pv * p.W + (int)pu : 0;
+                    fetch(r, j, ok, ok ? (uint32_t)((int)pv * p.W + (int)pu) : 0u);
                 }
             }
         }
+
+        if (q.mask != nullptr) {   // wave-uniform; ref: src/Engine.cpp:192-193
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
+            for (int r = 0; r < R; ++r)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t px = (uint32_t)pixel[r][j];
-                float d = q.depth[px];
-                if (q.mask != nullptr) d = d * (q.mask[px] >= 128 ? 1.0f : 0.0f);  // ref: src/Engine.cpp:192-193
-                dval[r][j] = d;
-            }
+                for (int j = 0; j < 4; ++j) dval[r][j] = dval[r][j] * (mval[r][j] >= 128 ? 1.0f : 0.0f);
         }
 
         // ---- depth tests (ref: src/tsdf.cu:46-49) ----------------------------------------------------
@@ -186,7 +195,7 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
                 const float d = dval[r][j];
                 const float df = d - pcz[r][j];
                 diff[r][j] = df;
-                const bool u = geo[r][j] & !((d <= 0.0f) | (d > p.max_depth)) & !(df <= -p.trunc);
+                const bool u = !((d <= 0.0f) | (d > p.max_depth)) & !(df <= -p.trunc);
                 upd[r][j] = u;
                 rowany[r] |= u;
                 bandr[r] |= u & !(df >= p.trunc);
