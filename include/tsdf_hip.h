@@ -161,6 +161,9 @@ int tsdf_device_ptrs(tsdf_volume *vol, float **tsdf_dev, float **weight_dev);
 
 /* Number of voxels in this handle's slab: dim_x * dim_y * (z_end - z_begin). */
 int64_t tsdf_slab_voxels(const tsdf_volume *vol);
+/* Frames tsdf_integrate_frames_device / tsdf_integrate_sequence_timed apply per pass over this slab (1 when
+ * the selected kernel variant does not fuse frames). */
+int32_t tsdf_frames_per_launch(const tsdf_volume *vol);
 
 /* Copy of the configuration the handle was created with. */
 int tsdf_get_config(const tsdf_volume *vol, tsdf_config *out);

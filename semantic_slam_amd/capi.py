@@ -19,7 +19,7 @@ ABI_SYMBOLS = [
     "tsdf_integrate_u16", "tsdf_convert_depth_u16",
     "tsdf_integrate_device", "tsdf_integrate_cam2base", "tsdf_integrate_masked_device",
     "tsdf_integrate_frames_device",
-    "tsdf_sync", "tsdf_download", "tsdf_copy_slices", "tsdf_upload", "tsdf_refresh_summary", "tsdf_device_ptrs", "tsdf_slab_voxels",
+    "tsdf_sync", "tsdf_download", "tsdf_copy_slices", "tsdf_upload", "tsdf_refresh_summary", "tsdf_device_ptrs", "tsdf_slab_voxels", "tsdf_frames_per_launch",
     "tsdf_get_config", "tsdf_last_cam2base", "tsdf_set_stream", "tsdf_get_stream",
     "tsdf_count_surface", "tsdf_extract_surface", "tsdf_extract_crossings", "tsdf_extract_mesh", "tsdf_save_mesh_ply", "tsdf_save_ply", "tsdf_save_bin", "tsdf_load_bin", "tsdf_save_state", "tsdf_load_state",
     "tsdf_integrate_sequence_timed", "tsdf_probe_stream", "tsdf_selftest_fastdiv", "tsdf_selftest_round", "tsdf_set_kernel_variant", "tsdf_last_error",
@@ -78,6 +78,8 @@ def load():
     L.tsdf_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     L.tsdf_slab_voxels.argtypes = [vp]
     L.tsdf_slab_voxels.restype = C.c_int64
+    L.tsdf_frames_per_launch.argtypes = [vp]
+    L.tsdf_frames_per_launch.restype = C.c_int32
     L.tsdf_get_config.argtypes = [vp, C.POINTER(TsdfConfig)]
     L.tsdf_last_cam2base.argtypes = [vp, vp]
     L.tsdf_set_stream.argtypes = [vp, vp]
@@ -231,6 +233,11 @@ class Volume:
     @property
     def n_voxels(self):
         return int(self.lib.tsdf_slab_voxels(self._h))
+
+    @property
+    def frames_per_launch(self):
+        """Frames a sequence call applies per pass over this slab (1 when the kernel variant does not fuse)."""
+        return int(self.lib.tsdf_frames_per_launch(self._h))
 
     @property
     def slab_shape(self):

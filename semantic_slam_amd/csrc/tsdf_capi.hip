@@ -176,7 +176,7 @@ tsdfk::IntegrateParams make_params(const tsdf_volume *v, const float *depth_dev,
 // Kernel variants (tsdf_set_kernel_variant):
 //   0        default: integrate_tile<2, elide, nt, summary, fast> when dim_x % 4 == 0, else the scalar
 //            kernel; frame sequences (tsdf_integrate_frames_device, ..._sequence_timed) go through
-//            integrate_multi, up to 4 frames per pass over the volume
+//            integrate_multi_inline, up to kMaxFramesPerLaunch (32) frames per pass over the volume
 //   3        as 0 but one launch per frame even for sequences
 //   4        as 0 with integrate_multi<R=2> (experiment; the default fuses with R=1)
 //   5        as 0 with an XCD-aware workgroup order (experiment)
@@ -401,14 +401,22 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
     return TSDF_OK;
 }
 
-// A sequence of frames: fused kMaxFramesPerLaunch at a time when the default kernel is selected.
+// Frames applied per pass over the slab.  Per frame the time is a + b / n: the weights are read and written,
+// the summary word and the voxel coordinates set up, the launch filled and drained once per pass (b), and
+// 512^3 measures 0.156 / 0.141 / 0.136 / 0.132 ms per frame at n = 4 / 8 / 16 / 32 (a = 0.129).
+int frames_per_launch(const tsdf_volume *)
+{
+    return tsdfk::kMaxFramesPerLaunch;
+}
+
+// A sequence of frames: fused frames_per_launch() at a time when the default kernel is selected.
 int integrate_frames(tsdf_volume *v, const float *const *depth_dev, const uint8_t *const *masks_dev,
                      const float *cam2world, int n_frames)
 {
     const bool fuse = (v->variant == 0 || (v->variant >= 4 && v->variant <= 6)) && v->cfg.dim_x % 4 == 0;
     int rc = TSDF_OK;
     for (int k = 0; k < n_frames && rc == TSDF_OK;) {
-        const int n = fuse ? std::min(tsdfk::kMaxFramesPerLaunch, n_frames - k) : 1;
+        const int n = fuse ? std::min(frames_per_launch(v), n_frames - k) : 1;
         float c2b[16 * tsdfk::kMaxFramesPerLaunch];
         for (int i = 0; i < n; ++i) compose_cam2base(v, cam2world + 16 * (k + i), c2b + 16 * i);
         if (fuse) rc = launch_multi(v, depth_dev + k, masks_dev ? masks_dev + k : nullptr, c2b, n);
@@ -753,6 +761,13 @@ int tsdf_device_ptrs(tsdf_volume *v, float **tsdf_dev, float **weight_dev)
 }
 
 int64_t tsdf_slab_voxels(const tsdf_volume *v) { return v ? v->n_vox : 0; }
+
+int32_t tsdf_frames_per_launch(const tsdf_volume *v)
+{
+    if (!v) return 0;
+    const bool fuse = (v->variant == 0 || (v->variant >= 4 && v->variant <= 6)) && v->cfg.dim_x % 4 == 0;
+    return fuse ? frames_per_launch(v) : 1;
+}
 
 int tsdf_get_config(const tsdf_volume *v, tsdf_config *out)
 {

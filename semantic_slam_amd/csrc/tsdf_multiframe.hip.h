@@ -17,7 +17,7 @@
 
 namespace tsdfk {
 
-constexpr int kMaxFramesPerLaunch = 4;
+constexpr int kMaxFramesPerLaunch = 32;
 
 struct FramePose {
     const float *depth;

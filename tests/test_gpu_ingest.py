@@ -71,7 +71,7 @@ def test_config2_1024_cube_on_the_fr3_trajectory(cuda, oracle):
 
 def test_config2_full_fr3_trajectory_fused(cuda, oracle):
     """All 194 keyframes of the reference's saved fr3_office run into a 1024^3 @ 2 mm volume through
-    tsdf_integrate_frames_device (4 frames per pass over the 8.6 GB volume), every frame's depth
+    tsdf_integrate_frames_device (up to 32 frames per pass over the 8.6 GB volume), every frame's depth
     resident in HBM.  Two 3-slice slabs are replayed by the oracle frame by frame and must match bit
     for bit; the frame count bounds every weight."""
     Twc = ingest.pose_inverse(np.load(GOLD)["Tcw"])
