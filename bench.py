@@ -109,12 +109,20 @@ def main():
             sys.exit(f"--gpus {args.gpus} needs: python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...")
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    # TSDF_BENCH_BACKEND=gloo: rehearsal of the N-rank path on a box with fewer GPUs than ranks (ranks share
+    # devices, the two scalars of the timing reduction travel through gloo); the driver's runs use RCCL.
+    backend = os.environ.get("TSDF_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     D = args.grid
     vs = {512: 0.005, 1024: 0.002}.get(D, 2.56 / D)
@@ -176,7 +184,7 @@ def main():
     fence()
     wall = time.perf_counter() - t0
 
-    tt = torch.tensor([wall, kernel_ms_total], dtype=torch.float64, device="cuda")
+    tt = torch.tensor([wall, kernel_ms_total], dtype=torch.float64, device="cpu" if backend == "gloo" else "cuda")
     if dist is not None:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     wall, kernel_ms_total = float(tt[0]), float(tt[1])
