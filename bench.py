@@ -258,7 +258,7 @@ def main():
             traffic = None
 
     line = {
-        "metric": f"Mvoxels/sec integrated, {D}^3 grid @ 640x480 depth; achieved HBM GB/s %peak",
+        "metric": f"Mvoxels/sec integrated, {D}\u00b3 grid @ 640\u00d7480 depth; achieved HBM GB/s %peak",   # BASELINE.json
         "value": round((n_global if args.emulate_world <= 1 else n_slab) * args.steps / wall / 1e6, 1),
         "unit": "Mvoxels/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
