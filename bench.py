@@ -340,6 +340,26 @@ def main():
                                    "value": round(n_global * n_host / dt / 1e6, 1), "unit": "Mvoxels/s",
                                    "note": "tsdf_integrate with a host depth pointer: memcpy to pinned staging + "
                                            "H2D copy + kernel per frame, Python ctypes call overhead included"}
+    if world == 1 and args.emulate_world <= 1 and args.variant == 0 and args.workload == "sfull":
+        # The same grid and kernel on the realistic workload of SURVEY.md section 8(d) (S-surf: a sphere in front of
+        # a wall seen from an orbit, uint16-quantised depth): only part of the volume is updated per frame and the
+        # TSDF values near the surfaces really change, so nothing about it is "all ones".
+        s_origin = synth.surf_volume(max(dims), vs, 1.0)
+        scene = synth.SurfScene(dims, vs, s_origin)
+        s_poses = np.stack([scene.pose(k, 64) for k in range(64)])
+        s_depth = torch.from_numpy(scene.depth(s_poses[0], quantize=True)).cuda()
+        with capi.Volume(capi.make_config(dims, vs, s_origin, device=local_rank)) as sv:
+            n_w, n_t = 2 * sv.frames_per_launch, 10 * sv.frames_per_launch
+            sv.integrate_sequence_timed(s_depth.data_ptr(), np.stack([s_poses[i % 64] for i in range(n_w)]))
+            ms_r = sv.integrate_sequence_timed(s_depth.data_ptr(), np.stack([s_poses[(n_w + i) % 64] for i in range(n_t)])) / n_t
+            _, w_r = sv.download()
+        upd_r = float(w_r.astype(np.float64).sum()) / (n_w + n_t)
+        del w_r
+        line["realistic_workload"] = {
+            "workload": f"ssurf {dims[0]}x{dims[1]}x{dims[2]} @ {vs * 1000:g} mm (sphere + wall, orbit of 64 poses, depth quantised at 1/5000 m)",
+            "ms_per_step": round(ms_r, 5), "value": round(n_global / ms_r / 1e3, 1), "unit": "Mvoxels/s",
+            "updated_fraction": round(upd_r / n_global, 4), "frames": n_t,
+            "algorithmic_GBps": round((16.0 * upd_r + 4.0 * H * W + 100.0) / (ms_r * 1e-3) / 1e9, 1)}
     if not args.no_cpu_baseline and world == 1 and args.emulate_world <= 1:
         per_slice = D * D if args.workload == "sfull" else None
         base, ref = cpu_baseline(args, dims, vs, origin, cfg, depth, poses, per_slice)
