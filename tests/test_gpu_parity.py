@@ -426,3 +426,41 @@ def test_checkpoint_resume(cuda, oracle, tmp_path):
     with capi.Volume(capi.make_config((32, 32, 32), vs, origin)) as c:
         with pytest.raises(capi.TsdfError):
             c.load_state(str(tmp_path / "half.state"))   # wrong slab is refused
+
+
+@pytest.mark.parametrize("dims", [(256, 24, 20), (200, 24, 20), (37, 20, 16)])   # row mapping, flat mapping, scalar kernel
+def test_non_finite_depth_samples(cuda, oracle, dims):
+    """NaN depth passes both depth tests of the reference (every comparison with NaN is false, ref: src/tsdf.cu:46,49)
+    and updates with dist = fmin(1, NaN) = 1; +-inf, -0, denormals and the 6 m boundary take the ordinary branches.
+    One launch per frame, fused launches and the first-version kernel must all reproduce that (the oracle is checked
+    against the reference's own body on the same kind of input in tests/test_oracle_vs_ref.py)."""
+    rng = np.random.default_rng(23)
+    vs = 2.0 / dims[0]
+    origin = synth.surf_volume(dims[0], vs, 0.6)
+    cfg = capi.make_config(dims, vs, origin)
+    sc = synth.SurfScene(dims, vs, origin)
+    odd = np.array([np.nan, np.inf, -np.inf, -0.0, 1e-42, -1e-42, 6.0, np.nextafter(np.float32(6.0), np.float32(7.0))], np.float32)
+    frames = []
+    for k in range(5):
+        c2w = sc.pose(k, 8)
+        depth = sc.depth(c2w, quantize=True)
+        depth[rng.integers(0, 480, 60000), rng.integers(0, 640, 60000)] = rng.choice(odd, 60000)
+        frames.append((c2w, depth))
+    ref_t, ref_w = oracle.init_grid(dims)
+    for c2w, depth in frames:
+        oracle.integrate(cfg.cam_K, c2w, depth, dims, origin, vs, cfg.trunc_margin, ref_t, ref_w)
+    assert np.isfinite(ref_t).all() and ref_w.max() >= 3
+    keep = [dev(cuda, d) for _, d in frames]
+    poses = np.stack([c for c, _ in frames])
+    for variant, fused in ((0, False), (0, True), (2, False), (17, False)):
+        if dims[0] % 4 and (fused or variant):
+            continue
+        with capi.Volume(cfg) as vol:
+            vol.set_kernel_variant(variant)
+            if fused:
+                vol.integrate_frames_device([d.data_ptr() for d in keep], poses)
+            else:
+                for d, c2w in zip(keep, poses):
+                    vol.integrate_device(d.data_ptr(), c2w)
+            t, w = vol.download()
+        assert_parity(t, w, ref_t, ref_w)

@@ -51,3 +51,25 @@ def test_degenerate_poses_match(oracle):
         oracle.integrate(K, c2b, depth, dims, origin, vs, 0.25, t1, w1)
         ref.integrate(K, c2b, depth, dims, origin, vs, 0.25, t2, w2)
         assert np.array_equal(w1, w2) and np.array_equal(t1.view(np.uint32), t2.view(np.uint32))
+
+
+def test_non_finite_depth_samples_match(oracle):
+    """NaN passes both of the reference's depth tests (ref: src/tsdf.cu:46,49 -- every comparison with NaN is false)
+    and updates the voxel with dist = fmin(1, NaN) = 1; +-inf, negative and denormal samples take the ordinary
+    branches.  The restatement must do exactly the same."""
+    ref = Ref()
+    rng = np.random.default_rng(11)
+    dims, vs = (40, 36, 30), 0.02
+    origin = synth.surf_volume(max(dims), vs, 0.6)
+    sc = synth.SurfScene(dims, vs, origin)
+    t1, w1 = oracle.init_grid(dims)
+    t2, w2 = t1.copy(), w1.copy()
+    odd = np.array([np.nan, np.inf, -np.inf, -0.0, 1e-42, -1e-42, 6.0, np.nextafter(np.float32(6.0), np.float32(7.0))], np.float32)
+    for k in range(4):
+        c2b = sc.pose(k, 8)
+        depth = sc.depth(c2b, quantize=True)
+        depth[rng.integers(0, 480, 20000), rng.integers(0, 640, 20000)] = rng.choice(odd, 20000)
+        oracle.integrate(synth.TUM_K, c2b, depth, dims, origin, vs, 0.1, t1, w1, threads=3)
+        ref.integrate(synth.TUM_K, c2b, depth, dims, origin, vs, 0.1, t2, w2, threads=2)
+    assert np.array_equal(w1, w2) and np.array_equal(t1.view(np.uint32), t2.view(np.uint32))
+    assert np.isfinite(t1).all() and w1.max() >= 3
