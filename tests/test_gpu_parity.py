@@ -464,3 +464,35 @@ def test_non_finite_depth_samples(cuda, oracle, dims):
                     vol.integrate_device(d.data_ptr(), c2w)
             t, w = vol.download()
         assert_parity(t, w, ref_t, ref_w)
+
+
+@pytest.mark.parametrize("dims", [(256, 12, 12), (12, 12, 12)])   # row mapping (fast-projection candidates), flat mapping
+def test_degenerate_poses(cuda, oracle, dims):
+    """Zero, vanishing, huge, NaN and infinite pose entries: the host bounds send them down the generic IEEE-division
+    path, which takes the same branches as the reference body (tests/test_oracle_vs_ref.py::test_degenerate_poses_match
+    pins the oracle on these), one frame per launch and fused."""
+    vs = 0.6 / dims[0]
+    origin = np.array([-0.3, -0.3, -0.3], np.float32)
+    cfg = capi.make_config(dims, vs, origin)
+    depth = np.full((480, 640), 1.0, np.float32)
+    nan_pose = synth.identity_pose(); nan_pose[5] = np.nan
+    inf_pose = synth.identity_pose(); inf_pose[3] = np.inf
+    poses = [np.zeros(16, np.float32), synth.make_pose(np.eye(3) * 1e-30, [0, 0, 0]), synth.make_pose(np.eye(3) * 1e30, [0, 0, 0]),
+             synth.make_pose(np.eye(3), [0, 0, 1e20]), synth.make_pose(np.eye(3) * 1e-20, [0, 0, -1e-20]), nan_pose, inf_pose,
+             synth.make_pose(synth.rot_x(0.2), [0.0, 0.0, -0.9]), synth.identity_pose()]
+    rt, rw = oracle.init_grid(dims)
+    with np.errstate(all="ignore"):
+        c2bs = [oracle.cam2base(synth.identity_pose(), p) for p in poses]
+    for c2b in c2bs:
+        oracle.integrate(cfg.cam_K, c2b, depth, dims, origin, vs, cfg.trunc_margin, rt, rw)
+    assert rw.max() >= 1
+    d = dev(cuda, depth)
+    with capi.Volume(cfg) as vol:
+        for p in poses:
+            vol.integrate_device(d.data_ptr(), p)
+        t, w = vol.download()
+    assert np.array_equal(w, rw, equal_nan=True) and np.array_equal(t.view(np.uint32), rt.view(np.uint32))
+    with capi.Volume(cfg) as vol:
+        vol.integrate_frames_device([d.data_ptr()] * len(poses), np.stack(poses))
+        t, w = vol.download()
+    assert np.array_equal(w, rw, equal_nan=True) and np.array_equal(t.view(np.uint32), rt.view(np.uint32))
