@@ -496,3 +496,27 @@ def test_degenerate_poses(cuda, oracle, dims):
         vol.integrate_frames_device([d.data_ptr()] * len(poses), np.stack(poses))
         t, w = vol.download()
     assert np.array_equal(w, rw, equal_nan=True) and np.array_equal(t.view(np.uint32), rt.view(np.uint32))
+
+
+def test_image_larger_than_2_pow_24_pixels(cuda, oracle):
+    """4200 x 4000 pixels: the pixel index is no longer exact in fp32, so the host withdraws the fast projection
+    (fast_ok) and every launch runs the generic path; the 32-bit byte offset of the gather still holds (< 2^30 pixels)."""
+    h, w = 4000, 4200
+    assert h * w > 1 << 24
+    dims, vs = (64, 48, 24), 0.02
+    origin = synth.surf_volume(64, vs, 0.8)
+    K = np.array([3500.0, 0, 2100.3, 0, 3500.0, 1999.6, 0, 0, 1], np.float32)
+    cfg = capi.make_config(dims, vs, origin, K=K, im_height=h, im_width=w)
+    rng = np.random.default_rng(3)
+    depth = rng.uniform(0.5, 2.5, (h, w)).astype(np.float32)
+    poses = [synth.identity_pose(), synth.make_pose(synth.rot_y(0.1), [0.1, 0.0, 0.0]), synth.make_pose(synth.rot_x(-0.05), [0.0, 0.05, 0.1])]
+    rt, rw = oracle.init_grid(dims)
+    for p in poses:
+        oracle.integrate(K, p, depth, dims, origin, vs, cfg.trunc_margin, rt, rw)
+    assert rw.sum() > 0.3 * rw.size
+    d = dev(cuda, depth)
+    with capi.Volume(cfg) as vol:
+        vol.integrate_device(d.data_ptr(), poses[0])
+        vol.integrate_frames_device([d.data_ptr()] * 2, np.stack(poses[1:]))
+        t, wgt = vol.download()
+    assert_parity(t, wgt, rt, rw)
