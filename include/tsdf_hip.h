@@ -274,6 +274,17 @@ int tsdf_selftest_round(int32_t device, uint64_t *mismatches, float first_bad[4]
 int tsdf_set_kernel_variant(tsdf_volume *vol, int32_t variant);
 
 /*
+ * Integrate AND label fusion of a known sequence of frames in the same passes over the volume: identical to
+ * calling tsdf_integrate_device and tsdf_integrate_labels_device for every frame in order, but the label
+ * evidence reuses the projection and depth tests Integrate has just made (the separate sweep recomputes
+ * them).  Needs dim_x % 4 == 0 and tsdf_labels_enable.  All pointers are device pointers that stay valid
+ * until the stream has run the launches.
+ */
+int tsdf_integrate_frames_labels_device(tsdf_volume *vol, const float *const *depth_dev,
+                                        const uint16_t *const *label_im_dev, const float *const *score_im_dev,
+                                        const float *cam2world, int32_t n_frames);
+
+/*
  * Per-voxel semantic-label fusion (BASELINE config 5).  Not a function of the reference's TSDF:
  * the reference fuses instance evidence per sparse ObjectPoint -- Fp += score inside a mask of the
  * point's object, Bp += score otherwise, P = Fp/(Fp+Bp), dropped below a threshold

@@ -24,7 +24,8 @@ ABI_SYMBOLS = [
     "tsdf_count_surface", "tsdf_extract_surface", "tsdf_extract_crossings", "tsdf_extract_mesh", "tsdf_save_mesh_ply", "tsdf_save_ply", "tsdf_save_bin", "tsdf_load_bin", "tsdf_save_state", "tsdf_load_state",
     "tsdf_integrate_sequence_timed", "tsdf_probe_stream", "tsdf_selftest_fastdiv", "tsdf_selftest_round", "tsdf_set_kernel_variant", "tsdf_last_error",
     "tsdf_version", "tsdf_multiply_matrix", "tsdf_invert_matrix",
-    "tsdf_labels_enable", "tsdf_compose_labels", "tsdf_integrate_labels_device", "tsdf_download_labels",
+    "tsdf_labels_enable", "tsdf_compose_labels", "tsdf_integrate_labels_device", "tsdf_integrate_frames_labels_device",
+    "tsdf_download_labels",
     "tsdf_object_origin", "tsdf_batch_create", "tsdf_batch_destroy", "tsdf_batch_size", "tsdf_batch_volume",
     "tsdf_batch_integrate_device", "tsdf_batch_sync",
 ]
@@ -108,6 +109,7 @@ def load():
     L.tsdf_compose_labels.argtypes = [vp, vp, vp, vp, C.c_int32, vp, vp]
     L.tsdf_integrate_labels_device.argtypes = [vp, vp, vp, vp, vp]
     L.tsdf_download_labels.argtypes = [vp, vp, vp, vp]
+    L.tsdf_integrate_frames_labels_device.argtypes = [vp, vp, vp, vp, vp, C.c_int32]
     L.tsdf_object_origin.argtypes = [C.c_int32, vp, vp, C.c_int32, C.c_int32, vp, vp]
     L.tsdf_batch_create.argtypes = [C.POINTER(TsdfConfig), C.c_int32, C.POINTER(vp)]
     L.tsdf_batch_destroy.argtypes = [vp]
@@ -361,6 +363,16 @@ class Volume:
         p = _f32(cam2world, 16)
         check(self.lib.tsdf_integrate_labels_device(self._h, depth_ptr, label_im_ptr, score_im_ptr, p.ctypes.data),
               "tsdf_integrate_labels_device")
+
+    def integrate_frames_labels_device(self, depth_ptrs, label_im_ptrs, score_im_ptrs, poses):
+        """Integrate + label fusion of a known sequence in the same passes == integrate_device + integrate_labels_device
+        per frame."""
+        p = _f32(np.asarray(poses, dtype=np.float32))
+        n = p.size // 16
+        assert len(depth_ptrs) == len(label_im_ptrs) == len(score_im_ptrs) == n
+        arr = lambda xs: (C.c_void_p * n)(*[C.c_void_p(x) for x in xs])
+        check(self.lib.tsdf_integrate_frames_labels_device(self._h, arr(depth_ptrs), arr(label_im_ptrs), arr(score_im_ptrs),
+                                                           p.ctypes.data, n), "tsdf_integrate_frames_labels_device")
 
     def download_labels(self):
         n = self.n_voxels

@@ -222,7 +222,8 @@ int rebuild_summary(tsdf_volume *v)
     return TSDF_OK;
 }
 
-int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *const *masks_dev, const float *c2b, int n);
+int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *const *masks_dev, const float *c2b, int n,
+                 const uint16_t *const *label_ims = nullptr, const float *const *score_ims = nullptr);
 
 // Queue one Integrate launch.  Shapes are validated at tsdf_create, so the grid covers exactly
 // the slab and every access stays inside the two allocations.
@@ -315,8 +316,9 @@ void compose_cam2base(const tsdf_volume *v, const float *cam2world, float *c2b)
 }
 
 // n frames (n <= kMaxFramesPerLaunch) in one pass over the slab.  c2b: n x 16 relative poses.
+// label_ims / score_ims (both or neither): the frames' label evidence is fused in the same pass (LABELS kernels).
 int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *const *masks_dev,
-                 const float *c2b, int n)
+                 const float *c2b, int n, const uint16_t *const *label_ims, const float *const *score_ims)
 {
     const tsdf_config &c = v->cfg;
     const int nz = c.z_end - c.z_begin;
@@ -329,8 +331,10 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
         fp.rz0 = q.rz0; fp.rz1 = q.rz1; fp.rz2 = q.rz2;
         fp.tx = q.tx; fp.ty = q.ty; fp.tz = q.tz;
         fp.fast_ok = q.fast_ok; fp.cz_margin = q.cz_margin;
+        fp.label_im = label_ims ? label_ims[f] : nullptr;
+        fp.score_im = label_ims ? score_ims[f] : nullptr;
     };
-    if (n == 1) {   // pose by value: nothing to stage
+    if (n == 1 && !label_ims) {   // pose by value: nothing to stage
         tsdfk::IntegrateParams common = make_params(v, depth_dev[0], nullptr, c2b, 4);
         tsdfk::FramePose pose;
         fill_pose(pose, 0);
@@ -350,13 +354,20 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
     std::memcpy(v->last_cam2base, c2b + 16 * (n - 1), sizeof v->last_cam2base);
     v->flags_known_zero = false;   // integrate_multi maintains the summary
     dim3 block(64, 4, 1);
-    if (v->variant != 4 && v->variant != 5 && v->variant != 6) {   // frame blocks in the kernarg: nothing staged
+    if (label_ims || (v->variant != 4 && v->variant != 5 && v->variant != 6)) {   // frame blocks in the kernarg: nothing staged
         tsdfk::MultiParamsInline mi;
         mi.common = make_params(v, depth_dev[0], nullptr, c2b, 4);
         mi.n_frames = n;
         for (int f = 0; f < n; ++f) fill_pose(mi.frames[f], f);
         for (int f = n; f < tsdfk::kMaxFramesPerLaunch; ++f) mi.frames[f] = mi.frames[0];
-        if (v->flat) {
+        mi.labels.label = v->d_label; mi.labels.fp = v->d_fp; mi.labels.bp = v->d_bp; mi.labels.prob_thd = v->prob_thd;
+        if (label_ims && v->flat) {
+            dim3 grid((v->chunks_per_slice + 3) / 4, 1, nz);
+            hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, true, true>), grid, block, 0, v->stream, mi);
+        } else if (label_ims) {
+            dim3 grid((mi.common.xgroups + 63) / 64, (c.dim_y + 3) / 4, nz);
+            hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, true>), grid, block, 0, v->stream, mi);
+        } else if (v->flat) {
             dim3 grid((v->chunks_per_slice + 3) / 4, 1, nz);
             hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, true>), grid, block, 0, v->stream, mi);
         } else {
@@ -678,6 +689,27 @@ int tsdf_integrate_frames_device(tsdf_volume *v, const float *const *depth_dev, 
     int rc = bind_device(v);
     if (rc) return rc;
     return integrate_frames(v, depth_dev, masks_dev, cam2world, n_frames);
+}
+
+int tsdf_integrate_frames_labels_device(tsdf_volume *v, const float *const *depth_dev, const uint16_t *const *label_im_dev,
+                                        const float *const *score_im_dev, const float *cam2world, int32_t n_frames)
+{
+    if (!v || !depth_dev || !label_im_dev || !score_im_dev || !cam2world || n_frames < 0)
+        return fail(TSDF_ERR_INVALID, "tsdf_integrate_frames_labels_device: bad argument");
+    if (!v->d_label) return fail(TSDF_ERR_INVALID, "tsdf_integrate_frames_labels_device: call tsdf_labels_enable first");
+    for (int k = 0; k < n_frames; ++k)
+        if (!depth_dev[k] || !label_im_dev[k] || !score_im_dev[k])
+            return fail(TSDF_ERR_INVALID, "tsdf_integrate_frames_labels_device: frame %d has a NULL image", k);
+    int rc = bind_device(v);
+    if (rc) return rc;
+    for (int k = 0; k < n_frames && rc == TSDF_OK;) {
+        const int n = std::min(frames_per_launch(v), n_frames - k);
+        float c2b[16 * tsdfk::kMaxFramesPerLaunch];
+        for (int i = 0; i < n; ++i) compose_cam2base(v, cam2world + 16 * (k + i), c2b + 16 * i);
+        rc = launch_multi(v, depth_dev + k, nullptr, c2b, n, label_im_dev + k, score_im_dev + k);
+        k += n;
+    }
+    return rc;
 }
 
 int tsdf_integrate_masked_device(tsdf_volume *v, const float *depth_dev, const uint8_t *mask_dev,

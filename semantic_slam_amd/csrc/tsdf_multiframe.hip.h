@@ -25,6 +25,16 @@ struct FramePose {
     float rx0, rx1, rx2, ry0, ry1, ry2, rz0, rz1, rz2, tx, ty, tz;   // as IntegrateParams
     int fast_ok;
     float cz_margin;
+    // per-voxel label fusion of the same frame (LABELS kernels; both null = no label evidence in this frame)
+    const uint16_t *label_im;
+    const float *score_im;
+};
+
+// Slab arrays of the per-voxel label state (tsdf_labels.hip.h), for the LABELS kernels.
+struct LabelState {
+    uint16_t *label;
+    float *fp, *bp;
+    float prob_thd;
 };
 
 struct MultiParams {
@@ -41,6 +51,7 @@ struct MultiParamsInline {
     IntegrateParams common;
     FramePose frames[kMaxFramesPerLaunch];
     int n_frames;
+    LabelState labels;   // read by the LABELS kernels only
 };
 
 // FLAT: the lane's quad comes from the linear view of the slice (IntegrateParams::quads_per_slice):
@@ -48,10 +59,14 @@ struct MultiParamsInline {
 // not a multiple of 256 voxels no longer leave lanes idle (200-voxel rows: 50 of 64 lanes in the row
 // mapping).  b0 = block index within the slice (4 chunks per block).  Needs R == 1.
 // !FLAT: the row mapping of integrate_tile (b0, b1 = x-block, y-block), dim_x % 256 == 0.
-template <int R, bool NT, bool FLAT>
+// LABELS: the label evidence of each frame (tsdf_labels.hip.h: same rule, same voxels) is applied in the same
+// pass, from the projection and depth tests Integrate has just made -- the separate label sweep recomputes both.
+template <int R, bool NT, bool FLAT, bool LABELS = false>
 __device__ __forceinline__ void multi_body(const IntegrateParams &p, const FramePose *__restrict__ frames,
-                                           const int n_frames, const int b0, const int b1, const int lz)
+                                           const int n_frames, const int b0, const int b1, const int lz,
+                                           const LabelState ls = LabelState())
 {
+    static_assert(!LABELS || R == 1, "label fusion rides on the one-row kernel");
     static_assert(!FLAT || R == 1, "the flat mapping handles one quad per lane");
     int xg, gy0;
     size_t row0, flag0;
@@ -115,7 +130,9 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
         // has to survive until then.  The load is skipped (exec-masked), not redirected.
         // The mask byte is fetched with it and applied after all loads of the frame have been issued.
         int mval[R][4];
+        uint32_t pixel[LABELS ? R : 1][4];   // (LABELS) the voxel's pixel, for the label and score images
         auto fetch = [&](const int r, const int j, const bool ok, const uint32_t px) {
+            if constexpr (LABELS) pixel[r][j] = px;
             float d = 0.0f;
             int m = 255;
             if (ok) {
@@ -205,6 +222,46 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
         }
         if (__ballot(any) == 0ull) continue;   // this frame touches nothing here
 
+        // ---- label evidence of this frame (tsdf_labels.hip.h: voxels observed inside the truncation band) ------
+        if constexpr (LABELS) {
+            if (q.label_im != nullptr && __ballot(band) != 0ull) {
+                uint16_t lab_in[4];
+                float sc_in[4];
+                bool hit = false;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool seen = upd[0][j] & (diff[0][j] < p.trunc);
+                    lab_in[j] = 0;
+                    sc_in[j] = 0.0f;
+                    if (seen) { lab_in[j] = q.label_im[pixel[0][j]]; sc_in[j] = q.score_im[pixel[0][j]]; }
+                    hit |= lab_in[j] != 0;
+                }
+                if (hit) {
+                    ushort4 L4 = *reinterpret_cast<const ushort4 *>(ls.label + row0);
+                    float4 F4 = *reinterpret_cast<const float4 *>(ls.fp + row0);
+                    float4 B4 = *reinterpret_cast<const float4 *>(ls.bp + row0);
+                    uint16_t L[4] = {L4.x, L4.y, L4.z, L4.w};
+                    float Fv[4] = {F4.x, F4.y, F4.z, F4.w}, Bv[4] = {B4.x, B4.y, B4.z, B4.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint16_t l = lab_in[j];
+                        const float sc = sc_in[j];
+                        if (l == 0) continue;
+                        if (L[j] == 0) { L[j] = l; Fv[j] = sc; Bv[j] = 0.0f; }
+                        else if (L[j] == l) { Fv[j] = Fv[j] + sc; }
+                        else {
+                            Bv[j] = Bv[j] + sc;
+                            if (Fv[j] / (Fv[j] + Bv[j]) < ls.prob_thd) { L[j] = l; Fv[j] = sc; Bv[j] = 0.0f; }
+                        }
+                    }
+                    ushort4 Lo; Lo.x = L[0]; Lo.y = L[1]; Lo.z = L[2]; Lo.w = L[3];
+                    *reinterpret_cast<ushort4 *>(ls.label + row0) = Lo;
+                    *reinterpret_cast<float4 *>(ls.fp + row0) = make_float4(Fv[0], Fv[1], Fv[2], Fv[3]);
+                    *reinterpret_cast<float4 *>(ls.bp + row0) = make_float4(Bv[0], Bv[1], Bv[2], Bv[3]);
+                }
+            }
+        }
+
         // ---- first touch: bring the quads in -------------------------------------------------------
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -290,7 +347,7 @@ __global__ __launch_bounds__(256, R == 2 ? 6 : 1) void integrate_multi(MultiPara
     multi_body<R, NT, FLAT>(mp.common, mp.frames, mp.n_frames, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
-template <int R, bool NT, bool FLAT>
+template <int R, bool NT, bool FLAT, bool LABELS = false>
 __global__ __launch_bounds__(256, R == 2 ? 6 : 1) void integrate_multi_inline(MultiParamsInline mp)
 {
     // the single by-value parameter starts the kernarg segment (offset 0)
@@ -298,7 +355,8 @@ __global__ __launch_bounds__(256, R == 2 ? 6 : 1) void integrate_multi_inline(Mu
     kernarg_ptr base = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
     typedef const FramePose __attribute__((address_space(4))) *frames_ptr;
     frames_ptr frames = (frames_ptr)(base + offsetof(MultiParamsInline, frames));
-    multi_body<R, NT, FLAT>(mp.common, (const FramePose *)frames, mp.n_frames, blockIdx.x, blockIdx.y, blockIdx.z);
+    multi_body<R, NT, FLAT, LABELS>(mp.common, (const FramePose *)frames, mp.n_frames, blockIdx.x, blockIdx.y, blockIdx.z,
+                                    mp.labels);
 }
 
 // Experiment (variant 5): XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs, so

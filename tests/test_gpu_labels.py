@@ -103,3 +103,47 @@ def test_config4_slab_of_2048_cube_with_labels(cuda, oracle):
             assert np.array_equal(gw, sw) and np.array_equal(gt.view(np.uint32), st.view(np.uint32))
             assert np.array_equal(lab[lo:hi], sl) and np.array_equal(fp[lo:hi], sf) and np.array_equal(bp[lo:hi], sb)
     assert seen > 1000 and np.count_nonzero(lab) > 10000, (seen, int(np.count_nonzero(lab)))
+
+
+@pytest.mark.parametrize("dims,n_frames", [((256, 40, 24), 7), ((200, 40, 24), 35)])   # row mapping; flat mapping across a pass boundary
+def test_fused_integrate_and_labels_equal_separate_passes(cuda, oracle, dims, n_frames):
+    """tsdf_integrate_frames_labels_device == tsdf_integrate_device + tsdf_integrate_labels_device per frame == the
+    oracle's two functions, bit for bit, for the TSDF, the weights and the three label arrays."""
+    vs = 2.0 / dims[0]
+    origin = synth.surf_volume(dims[0], vs, 0.6)
+    cfg = capi.make_config(dims, vs, origin)
+    scene = synth.SurfScene(dims, vs, origin)
+    rng = np.random.default_rng(n_frames)
+    n = dims[0] * dims[1] * dims[2]
+    ref_l, ref_f, ref_b = np.zeros(n, np.uint16), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    ref_t, ref_w = oracle.init_grid(dims)
+    frames = []
+    for k in range(n_frames):
+        c2w = scene.pose(k % 5, n=8)
+        depth = scene.depth(c2w, quantize=True)
+        masks, labels, scores = instance_masks(rng, 4)
+        if k % 3 == 2:
+            labels[:] = labels[::-1]
+        lab, sc = oracle.compose_labels(masks, labels, scores)
+        frames.append((c2w, depth, lab, sc))
+        oracle.integrate_labels(cfg.cam_K, c2w, depth, lab, sc, dims, origin, vs, cfg.trunc_margin, ref_l, ref_f, ref_b)
+        oracle.integrate(cfg.cam_K, c2w, depth, dims, origin, vs, cfg.trunc_margin, ref_t, ref_w)
+    assert np.count_nonzero(ref_l) > 1000 and np.count_nonzero(ref_b) > 50
+    keep = [(cuda.from_numpy(d).cuda(), cuda.from_numpy(l).cuda(), cuda.from_numpy(s_).cuda()) for _, d, l, s_ in frames]
+    poses = np.stack([f[0] for f in frames])
+    with capi.Volume(cfg) as vol:
+        vol.labels_enable(0.5)
+        vol.integrate_frames_labels_device([d.data_ptr() for d, _, _ in keep], [l.data_ptr() for _, l, _ in keep],
+                                           [s_.data_ptr() for _, _, s_ in keep], poses)
+        lab, fp, bp = vol.download_labels()
+        t, w = vol.download()
+    assert np.array_equal(w, ref_w) and np.array_equal(t.view(np.uint32), ref_t.view(np.uint32))
+    assert np.array_equal(lab, ref_l)
+    assert np.array_equal(fp.view(np.uint32), ref_f.view(np.uint32)) and np.array_equal(bp.view(np.uint32), ref_b.view(np.uint32))
+    with capi.Volume(cfg) as vol:   # the separate passes give the same arrays
+        vol.labels_enable(0.5)
+        for (c2w, _, _, _), (d, l, s_) in zip(frames, keep):
+            vol.integrate_device(d.data_ptr(), c2w)
+            vol.integrate_labels_device(d.data_ptr(), l.data_ptr(), s_.data_ptr(), c2w)
+        lab2, fp2, bp2 = vol.download_labels()
+    assert np.array_equal(lab2, lab) and np.array_equal(fp2.view(np.uint32), fp.view(np.uint32)) and np.array_equal(bp2.view(np.uint32), bp.view(np.uint32))

@@ -70,6 +70,28 @@ tc = (time.perf_counter() - t0) * 8
 print(f"label fusion pass (compose 6 masks + 512^3 sweep): GPU {tg * 1e3:.3f} ms = {D ** 3 / tg / 1e6:.0f} Mvox/s  "
       f"CPU oracle (1 thread, 64-slice sample x8) {tc * 1e3:.0f} ms")
 
+# Integrate + labels of a 64-frame sequence: fused passes against the two sweeps per frame
+seq = [scene.pose(k, 64) for k in range(64)]
+dptr, lptr, sptr = [d_dev.data_ptr()] * 64, [lab_dev.data_ptr()] * 64, [sc_dev.data_ptr()] * 64
+
+
+def fused_seq():
+    vol.integrate_frames_labels_device(dptr, lptr, sptr, np.stack(seq))
+    vol.sync()
+
+
+def separate_seq():
+    vol.integrate_frames_device(dptr, np.stack(seq))
+    for c2w in seq:
+        vol.integrate_labels_device(d_dev.data_ptr(), lab_dev.data_ptr(), sc_dev.data_ptr(), c2w)
+    vol.sync()
+
+
+tfu, _ = timeit(fused_seq, 3)
+tse, _ = timeit(separate_seq, 3)
+print(f"Integrate + label fusion, 64 frames at 512^3: fused passes {tfu / 64 * 1e3:.4f} ms/frame "
+      f"({D ** 3 / (tfu / 64) / 1e6:.0f} Mvox/s), fused Integrate + one label sweep per frame {tse / 64 * 1e3:.4f} ms/frame")
+
 raw = np.round(np.clip(frames[0][1], 0, 13.0) * 5000.0).astype(np.uint16)
 tu, _ = timeit(lambda: (vol.integrate_u16(raw, frames[0][0]), vol.sync()), 50)
 tf, _ = timeit(lambda: (vol.integrate(frames[0][1], frames[0][0]), vol.sync()), 50)
