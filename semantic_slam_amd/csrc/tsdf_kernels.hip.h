@@ -267,9 +267,6 @@ __device__ __forceinline__ void vol_store(float *p, float4 v)
     }
 }
 
-// Coarse frustum gate for the speculative loads: true unless the patch's four corners
-// (x0|x1, y0|y1 at slice gz) are all behind the camera or all beyond the same image edge by
-// more than one pixel.  Lanes 0..3 each project one corner; approximate arithmetic is fine.
 // depth[px] through a 32-bit byte offset from the wave-uniform base: the load takes the base from SGPRs
 // and the offset from one VGPR (global_load_dword v, v_off, s[base]) instead of a 64-bit address built
 // per voxel.  px < 2^30 pixels (tsdf_create refuses larger images), so px * 4 does not wrap.
@@ -285,6 +282,9 @@ __device__ __forceinline__ int pixel_index24(int iv, int W, int iu)
     return (int)(__umul24((unsigned)iv, (unsigned)W) + (unsigned)iu);
 }
 
+// Coarse frustum gate for the speculative loads: true unless the patch's four corners
+// (x0|x1, y0|y1 at slice gz) are all behind the camera or all beyond the same image edge by
+// more than one pixel.  Lanes 0..3 each project one corner; approximate arithmetic is fine.
 __device__ __forceinline__ bool patch_may_be_visible(const IntegrateParams &p, int x0, int x1, int y0,
                                                      int y1, int gz)
 {

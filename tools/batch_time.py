@@ -12,6 +12,7 @@ from semantic_slam_amd import capi, synth  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 E = int(sys.argv[2]) if len(sys.argv) > 2 else 200      # grid edge of every object volume
+use_masks = not (len(sys.argv) > 3 and sys.argv[3] == "nomask")
 rng = np.random.default_rng(0)
 cfgs = []
 for i in range(n):
@@ -23,7 +24,7 @@ mask = torch.full((480, 640), 255, dtype=torch.uint8).cuda()
 poses = [scene.pose(k, 8) for k in range(8)]
 frames = 200
 with capi.Batch(cfgs) as batch:
-    ptrs = [mask.data_ptr()] * n
+    ptrs = [mask.data_ptr()] * n if use_masks else None
     for k in range(10):
         batch.integrate_device(depth.data_ptr(), ptrs, poses[k % 8])
     batch.sync()
@@ -35,16 +36,16 @@ with capi.Batch(cfgs) as batch:
 vols = [capi.Volume(c) for c in cfgs]
 for k in range(10):
     for v in vols:
-        v.integrate_masked_device(depth.data_ptr(), mask.data_ptr(), poses[k % 8])
+        v.integrate_masked_device(depth.data_ptr(), mask.data_ptr(), poses[k % 8]) if use_masks else v.integrate_device(depth.data_ptr(), poses[k % 8])
 for v in vols:
     v.sync()
 t0 = time.perf_counter()
 for k in range(frames):
     for v in vols:
-        v.integrate_masked_device(depth.data_ptr(), mask.data_ptr(), poses[k % 8])
+        v.integrate_masked_device(depth.data_ptr(), mask.data_ptr(), poses[k % 8]) if use_masks else v.integrate_device(depth.data_ptr(), poses[k % 8])
 for v in vols:
     v.sync()
 ts = (time.perf_counter() - t0) / frames
 vox = n * E ** 3
-print(f"{n} volumes of {E}^3: batched {tb * 1e3:.3f} ms/frame ({vox / tb / 1e6:.0f} Mvox/s), "
+print(f"{n} volumes of {E}^3{'' if use_masks else ' (no masks)'}: batched {tb * 1e3:.3f} ms/frame ({vox / tb / 1e6:.0f} Mvox/s), "
       f"per-volume launches {ts * 1e3:.3f} ms/frame ({vox / ts / 1e6:.0f} Mvox/s), speed-up {ts / tb:.2f}x")
