@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="single-GPU rehearsal of one rank of an N-GPU job: integrate only rank 0's z-slab of N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the contract's timed region (for profiler runs: no streaming-variant, host-depth or "
+                         "S-surf companion legs, which launch more kernels after it)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
     return ap.parse_args()
 
@@ -280,7 +283,7 @@ def main():
         # the figure exceeds the HBM peak; "physical" prices the same launches by the bytes that really move.
         "roofline": {"bound": "hbm", "achieved": round(achieved_survey, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved_survey / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "kernel": "tsdfk::integrate_multi_inline<1,true,false>" if fused else
+                     "kernel": "tsdfk::integrate_multi_inline<1,true,false,false,false>" if fused else
                                ("tsdfk::integrate_tile<2,true,true,false,true,false,true>" if v == 3 else f"variant {v}"),
                      "frames_per_launch": fpl, "launches": launches,
                      "kernel_ms": round(kernel_ms, 5),
@@ -306,7 +309,7 @@ def main():
                                          "see streaming_variant for the access pattern's HBM rate when all 16 B move",
                      "note": "per-rank slab launch; kernel_ms = HIP-event time of the timed region / launches"},
     }
-    if world == 1 and args.variant == 0 and args.emulate_world <= 1:
+    if world == 1 and args.variant == 0 and args.emulate_world <= 1 and not args.no_extras:
         # The same workload through the plain streaming variant (no elision, no summary: all 16 B per
         # updated voxel really move).  This is the kernel to read as "how close to the HBM roofline
         # does the access pattern get"; the default kernel above is faster because it moves fewer bytes.
@@ -326,7 +329,7 @@ def main():
             "value": round(n_global / ms_s / 1e3, 1), "unit": "GB/s (value: Mvoxels/s)"}
         vol.set_kernel_variant(0)
         vol.reset()
-    if world == 1 and args.emulate_world <= 1:
+    if world == 1 and args.emulate_world <= 1 and not args.no_extras:
         # PCIe-inclusive rate of the reference-style call (tsdf_integrate: host depth pointer, staged
         # through the pinned ring, 1.2 MB H2D per frame).  Reported beside the headline, never as it.
         n_host = min(args.steps, 200)
@@ -340,7 +343,7 @@ def main():
                                    "value": round(n_global * n_host / dt / 1e6, 1), "unit": "Mvoxels/s",
                                    "note": "tsdf_integrate with a host depth pointer: memcpy to pinned staging + "
                                            "H2D copy + kernel per frame, Python ctypes call overhead included"}
-    if world == 1 and args.emulate_world <= 1 and args.variant == 0 and args.workload == "sfull":
+    if world == 1 and args.emulate_world <= 1 and args.variant == 0 and args.workload == "sfull" and not args.no_extras:
         # The same grid and kernel on the realistic workload of SURVEY.md section 8(d) (S-surf: a sphere in front of
         # a wall seen from an orbit, uint16-quantised depth): only part of the volume is updated per frame and the
         # TSDF values near the surfaces really change, so nothing about it is "all ones".

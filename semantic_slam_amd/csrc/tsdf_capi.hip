@@ -367,12 +367,18 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
         } else if (label_ims) {
             dim3 grid((mi.common.xgroups + 63) / 64, (c.dim_y + 3) / 4, nz);
             hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, true>), grid, block, 0, v->stream, mi);
-        } else if (v->flat) {
-            dim3 grid((v->chunks_per_slice + 3) / 4, 1, nz);
-            hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, true>), grid, block, 0, v->stream, mi);
         } else {
-            dim3 grid((mi.common.xgroups + 63) / 64, (c.dim_y + 3) / 4, nz);
-            hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false>), grid, block, 0, v->stream, mi);
+            bool any_mask = false;
+            for (int f = 0; f < n && masks_dev; ++f) any_mask = any_mask || masks_dev[f] != nullptr;
+            dim3 grid_flat((v->chunks_per_slice + 3) / 4, 1, nz), grid_rows((mi.common.xgroups + 63) / 64, (c.dim_y + 3) / 4, nz);
+            if (v->flat && any_mask)
+                hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, true, false, true>), grid_flat, block, 0, v->stream, mi);
+            else if (v->flat)
+                hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, true, false, false>), grid_flat, block, 0, v->stream, mi);
+            else if (any_mask)
+                hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, false, true>), grid_rows, block, 0, v->stream, mi);
+            else
+                hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, false, false>), grid_rows, block, 0, v->stream, mi);
         }
         HIP_TRY(hipGetLastError());
         return TSDF_OK;

@@ -61,7 +61,9 @@ struct MultiParamsInline {
 // !FLAT: the row mapping of integrate_tile (b0, b1 = x-block, y-block), dim_x % 256 == 0.
 // LABELS: the label evidence of each frame (tsdf_labels.hip.h: same rule, same voxels) is applied in the same
 // pass, from the projection and depth tests Integrate has just made -- the separate label sweep recomputes both.
-template <int R, bool NT, bool FLAT, bool LABELS = false>
+// MASKS = false: the host promises that no frame of the launch carries an instance mask, and the kernel holds
+// no mask bytes, defaults or null tests (2 of 44 VALU instructions per voxel-frame).
+template <int R, bool NT, bool FLAT, bool LABELS = false, bool MASKS = true>
 __device__ __forceinline__ void multi_body(const IntegrateParams &p, const FramePose *__restrict__ frames,
                                            const int n_frames, const int b0, const int b1, const int lz,
                                            const LabelState ls = LabelState())
@@ -129,7 +131,7 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
         // the depth test below exactly as the reference's `continue` does, so no separate validity flag
         // has to survive until then.  The load is skipped (exec-masked), not redirected.
         // The mask byte is fetched with it and applied after all loads of the frame have been issued.
-        int mval[R][4];
+        int mval[MASKS ? R : 1][4];
         uint32_t pixel[LABELS ? R : 1][4];   // (LABELS) the voxel's pixel, for the label and score images
         auto fetch = [&](const int r, const int j, const bool ok, const uint32_t px) {
             if constexpr (LABELS) pixel[r][j] = px;
@@ -137,10 +139,10 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
             int m = 255;
             if (ok) {
                 d = gather_f32(q.depth, px);
-                if (q.mask != nullptr) m = q.mask[px];
+                if constexpr (MASKS) if (q.mask != nullptr) m = q.mask[px];
             }
             dval[r][j] = d;
-            mval[r][j] = m;
+            if constexpr (MASKS) mval[r][j] = m;
         };
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -192,11 +194,13 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
             }
         }
 
-        if (q.mask != nullptr) {   // wave-uniform; ref: src/Engine.cpp:192-193
+        if constexpr (MASKS) {
+            if (q.mask != nullptr) {   // wave-uniform; ref: src/Engine.cpp:192-193
 #pragma unroll
-            for (int r = 0; r < R; ++r)
+                for (int r = 0; r < R; ++r)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) dval[r][j] = dval[r][j] * (mval[r][j] >= 128 ? 1.0f : 0.0f);
+                    for (int j = 0; j < 4; ++j) dval[r][j] = dval[r][j] * (mval[r][j] >= 128 ? 1.0f : 0.0f);
+            }
         }
 
         // ---- depth tests (ref: src/tsdf.cu:46-49) ----------------------------------------------------
@@ -347,7 +351,7 @@ __global__ __launch_bounds__(256, R == 2 ? 6 : 1) void integrate_multi(MultiPara
     multi_body<R, NT, FLAT>(mp.common, mp.frames, mp.n_frames, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
-template <int R, bool NT, bool FLAT, bool LABELS = false>
+template <int R, bool NT, bool FLAT, bool LABELS = false, bool MASKS = true>
 __global__ __launch_bounds__(256, R == 2 ? 6 : 1) void integrate_multi_inline(MultiParamsInline mp)
 {
     // the single by-value parameter starts the kernarg segment (offset 0)
@@ -355,8 +359,8 @@ __global__ __launch_bounds__(256, R == 2 ? 6 : 1) void integrate_multi_inline(Mu
     kernarg_ptr base = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
     typedef const FramePose __attribute__((address_space(4))) *frames_ptr;
     frames_ptr frames = (frames_ptr)(base + offsetof(MultiParamsInline, frames));
-    multi_body<R, NT, FLAT, LABELS>(mp.common, (const FramePose *)frames, mp.n_frames, blockIdx.x, blockIdx.y, blockIdx.z,
-                                    mp.labels);
+    multi_body<R, NT, FLAT, LABELS, MASKS>(mp.common, (const FramePose *)frames, mp.n_frames, blockIdx.x, blockIdx.y,
+                                           blockIdx.z, mp.labels);
 }
 
 // Experiment (variant 5): XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs, so
