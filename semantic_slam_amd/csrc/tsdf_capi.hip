@@ -363,10 +363,10 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
         mi.labels.label = v->d_label; mi.labels.fp = v->d_fp; mi.labels.bp = v->d_bp; mi.labels.prob_thd = v->prob_thd;
         if (label_ims && v->flat) {
             dim3 grid((v->chunks_per_slice + 3) / 4, 1, nz);
-            hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, true, true>), grid, block, 0, v->stream, mi);
+            hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, true, true, false>), grid, block, 0, v->stream, mi);
         } else if (label_ims) {
             dim3 grid((mi.common.xgroups + 63) / 64, (c.dim_y + 3) / 4, nz);
-            hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, true>), grid, block, 0, v->stream, mi);
+            hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, true, false>), grid, block, 0, v->stream, mi);
         } else {
             bool any_mask = false;
             for (int f = 0; f < n && masks_dev; ++f) any_mask = any_mask || masks_dev[f] != nullptr;
