@@ -151,11 +151,17 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
             for (int j = 0; j < 4; ++j) pcz[r][j] = az[j] + z1 + z2;
         }
         // corner test of the patch against the camera plane, see integrate_tile
-        const float cmin = fminf(fminf(pcz[0][0], pcz[0][3]), fminf(pcz[R - 1][0], pcz[R - 1][3]));
-        const float cmax = fmaxf(fmaxf(pcz[0][0], pcz[0][3]), fmaxf(pcz[R - 1][0], pcz[R - 1][3]));
-        const bool unsafe = !(cmin > q.cz_margin) & !(cmax < -q.cz_margin);
+        // (compares on the corners themselves: min/max would add two canonicalising moves and treat a NaN corner
+        // as absent; a NaN fails every compare here and sends the wavefront down the generic path)
+        bool all_front = (pcz[0][0] > q.cz_margin) & (pcz[0][3] > q.cz_margin);
+        bool all_behind = (pcz[0][0] < -q.cz_margin) & (pcz[0][3] < -q.cz_margin);
+        if constexpr (R > 1) {
+            all_front &= (pcz[R - 1][0] > q.cz_margin) & (pcz[R - 1][3] > q.cz_margin);
+            all_behind &= (pcz[R - 1][0] < -q.cz_margin) & (pcz[R - 1][3] < -q.cz_margin);
+        }
+        const bool unsafe = !(all_front | all_behind);
         if (q.fast_ok != 0 && __ballot(unsafe) == 0ull) {
-            const bool front = cmin > q.cz_margin;   // the sign of cz over the whole patch (corner test)
+            const bool front = all_front;   // the sign of cz over the whole patch (corner test)
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const bool row_ok = gy0 + r < p.dim_y;
