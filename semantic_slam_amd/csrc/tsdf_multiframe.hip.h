@@ -22,7 +22,9 @@ constexpr int kMaxFramesPerLaunch = 32;
 struct FramePose {
     const float *depth;
     const uint8_t *mask;     // may be null
-    float rx0, rx1, rx2, ry0, ry1, ry2, rz0, rz1, rz2, tx, ty, tz;   // as IntegrateParams
+    // as IntegrateParams; ordered so that the pairs the packed operations take -- (rx_k, ry_k), (tx, ty) -- sit in
+    // aligned SGPR pairs straight out of the scalar loads (no s_mov shuffles per frame)
+    float rx0, ry0, rx1, ry1, rx2, ry2, rz0, rz1, rz2, tz, tx, ty;
     int fast_ok;
     float cz_margin;
     // per-voxel label fusion of the same frame (LABELS kernels; both null = no label evidence in this frame)
