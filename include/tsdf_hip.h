@@ -164,6 +164,13 @@ int64_t tsdf_slab_voxels(const tsdf_volume *vol);
 /* Frames tsdf_integrate_frames_device / tsdf_integrate_sequence_timed apply per pass over this slab (1 when
  * the selected kernel variant does not fuse frames). */
 int32_t tsdf_frames_per_launch(const tsdf_volume *vol);
+/*
+ * Diagnostics of the fused path's per-wavefront patch classification (depth tile summaries): reads the
+ * counters {wavefront-frames that took the per-voxel path, that were updated as free space without projecting
+ * a voxel, that were skipped} accumulated since they were last enabled (counts_out may be NULL), then
+ * enables (and zeroes) or disables them.  Off by default; synchronises the stream.
+ */
+int tsdf_shortcut_stats(tsdf_volume *vol, int32_t enable, uint64_t counts_out[3]);
 
 /* Copy of the configuration the handle was created with. */
 int tsdf_get_config(const tsdf_volume *vol, tsdf_config *out);

@@ -88,6 +88,9 @@ struct tsdf_volume {
     int chunks_per_slice;  // ceil(dim_x*dim_y / 256)
     bool flat;             // dim_x % 256 != 0: summary-maintaining launches use the flat mapping
     bool flags_known_zero;
+    // depth tile summaries of the frames of one fused launch (allocated on first use), optional counters
+    float2 *d_tiles;
+    unsigned int *d_shortcut_stats;
     // scratch for surface extraction (allocated on first use)
     void *d_scratch;
     size_t scratch_bytes;
@@ -169,7 +172,32 @@ tsdfk::IntegrateParams make_params(const tsdf_volume *v, const float *depth_dev,
              (int64_t)c.im_width * c.im_height <= (1 << 24) &&   // pixel index exact in fp32
              c.im_width < (1 << 24) && c.im_height < (1 << 24);   // and its factors fit the 24-bit multiply
         p.fast_ok = ok ? 1 : 0;
+        // Patch classification (tsdf_multiframe.hip.h, classify_patch).  E_k bounds how far a voxel's d_k = (o_k +
+        // i*vs) - t_k, as rounded on the per-voxel path, lies from the affine function of the index (two roundings at
+        // the magnitude of the coordinate, one at that of the difference); eps bounds the error of a camera-frame
+        // coordinate on either path (those, through the rotation, plus five roundings at the magnitude b_i), twice.
+        double bmax = 0, eps = 0;
+        for (int i = 0; i < 3; ++i) {
+            double b = 0, e = 0;
+            for (int k = 0; k < 3; ++k) {
+                const double Ek = 1.2e-7 * (std::fabs(o[k]) + ext[k] + std::fabs(t[k])) + 6e-8 * dmax[k];
+                b += std::fabs(rows[i][k]) * dmax[k];
+                e += std::fabs(rows[i][k]) * Ek;
+            }
+            bmax = std::fmax(bmax, b);
+            eps = std::fmax(eps, 2.0 * (e + 3.0e-7 * b));
+        }
+        const bool sok = ok && bmax > 0 && eps < 1e30;
+        p.cz_short = sok ? (float)(std::fmax(bmax / 64.0, eps / 3.2e-5) * 1.0001) : 3.0e38f;
+        p.cz_pad = sok ? (float)(std::fmax(2.0 * eps, (double)p.cz_margin) * 1.0001) : 3.0e38f;
     }
+    p.tiles_w = (c.im_width + tsdfk::kTile - 1) / tsdfk::kTile;
+    p.tiles_h = (c.im_height + tsdfk::kTile - 1) / tsdfk::kTile;
+    // 0.5 (rounding to the pixel) + 1 (slack) + the projection error for cz >= cz_short: |fx| * (eps / cz) * (1 + |t|)
+    // with eps / cz <= 3.2e-5 and |t| <= 4 (W + |cx|) / |fx| for every corner that can matter
+    p.px_margin_u = (float)(1.5 + 3.2e-5 * (std::fabs((double)p.fx) + 4.0 * (c.im_width + std::fabs((double)p.cx))));
+    p.px_margin_v = (float)(1.5 + 3.2e-5 * (std::fabs((double)p.fy) + 4.0 * (c.im_height + std::fabs((double)p.cy))));
+    p.shortcut_stats = v->d_shortcut_stats;
     return p;
 }
 
@@ -181,6 +209,8 @@ tsdfk::IntegrateParams make_params(const tsdf_volume *v, const float *depth_dev,
 //   4        as 0 with integrate_multi<R=2> (experiment; the default fuses with R=1)
 //   5        as 0 with an XCD-aware workgroup order (experiment)
 //   6        as 0 with the frame blocks staged in device memory instead of the kernarg (A/B)
+//   8        as 0 with the per-wavefront patch classification from depth tile summaries (experiment: exact, but
+//            the classification costs as much as the per-voxel path it saves)
 //   1        scalar kernel integrate_rows<1> (any dim_x)
 //   2        first version integrate_rows<4> (one row per wavefront, no elision)
 //   16 + c   experiments: c = (rsel << 2) | (elide << 1) | nt, R = 1, 2, 4 for rsel = 0, 1, 2
@@ -235,7 +265,7 @@ int launch_integrate(tsdf_volume *v, const float *depth_dev, const uint8_t *mask
     if (nz == 0) return TSDF_OK;  // empty slab: nothing to do
     std::memcpy(v->last_cam2base, c2b, sizeof v->last_cam2base);
     int variant = v->variant;
-    if (variant == 0 || (variant >= 3 && variant <= 6)) variant = kDefaultTile;
+    if (variant == 0 || (variant >= 3 && variant <= 8)) variant = kDefaultTile;
     if (c.dim_x % 4 != 0) variant = 1;  // rows are not 16-byte aligned: scalar kernel
     if (v->flat && variant != 1 && variant != 2) {
         // rows that are not a multiple of 256 voxels: the flat mapping (every lane busy, summary kept)
@@ -333,6 +363,8 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
         fp.fast_ok = q.fast_ok; fp.cz_margin = q.cz_margin;
         fp.label_im = label_ims ? label_ims[f] : nullptr;
         fp.score_im = label_ims ? score_ims[f] : nullptr;
+        fp.tiles = nullptr;
+        fp.cz_short = q.cz_short; fp.cz_pad = q.cz_pad;
     };
     if (n == 1 && !label_ims) {   // pose by value: nothing to stage
         tsdfk::IntegrateParams common = make_params(v, depth_dev[0], nullptr, c2b, 4);
@@ -371,12 +403,30 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
             bool any_mask = false;
             for (int f = 0; f < n && masks_dev; ++f) any_mask = any_mask || masks_dev[f] != nullptr;
             dim3 grid_flat((v->chunks_per_slice + 3) / 4, 1, nz), grid_rows((mi.common.xgroups + 63) / 64, (c.dim_y + 3) / 4, nz);
+            const bool classify = !any_mask && v->variant == 8;   // experiment, see DESIGN.md section 4
+            if (classify) {
+                // depth tile summaries of the n frames (one small launch), then the kernel that consults them
+                const size_t per_frame = (size_t)mi.common.tiles_w * mi.common.tiles_h;
+                if (!v->d_tiles) HIP_TRY(hipMalloc((void **)&v->d_tiles, tsdfk::kMaxFramesPerLaunch * per_frame * sizeof(float2)));
+                tsdfk::TileSummaryParams tp;
+                for (int f = 0; f < tsdfk::kMaxFramesPerLaunch; ++f) tp.depth[f] = depth_dev[f < n ? f : 0];
+                tp.tiles = v->d_tiles;
+                tp.H = c.im_height; tp.W = c.im_width; tp.tiles_w = mi.common.tiles_w; tp.tiles_h = mi.common.tiles_h;
+                tp.max_depth = c.max_depth;
+                hipLaunchKernelGGL(tsdfk::depth_tile_summary, dim3((unsigned)per_frame, n), dim3(64), 0, v->stream, tp);
+                for (int f = 0; f < n; ++f) mi.frames[f].tiles = v->d_tiles + (size_t)f * per_frame;
+                for (int f = n; f < tsdfk::kMaxFramesPerLaunch; ++f) mi.frames[f] = mi.frames[0];
+            }
             if (v->flat && any_mask)
                 hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, true, false, true>), grid_flat, block, 0, v->stream, mi);
+            else if (v->flat && classify)
+                hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, true, false, false, true>), grid_flat, block, 0, v->stream, mi);
             else if (v->flat)
                 hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, true, false, false>), grid_flat, block, 0, v->stream, mi);
             else if (any_mask)
                 hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, false, true>), grid_rows, block, 0, v->stream, mi);
+            else if (classify)
+                hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, false, false, true>), grid_rows, block, 0, v->stream, mi);
             else
                 hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, false, false>), grid_rows, block, 0, v->stream, mi);
         }
@@ -430,7 +480,7 @@ int frames_per_launch(const tsdf_volume *)
 int integrate_frames(tsdf_volume *v, const float *const *depth_dev, const uint8_t *const *masks_dev,
                      const float *cam2world, int n_frames)
 {
-    const bool fuse = (v->variant == 0 || (v->variant >= 4 && v->variant <= 6)) && v->cfg.dim_x % 4 == 0;
+    const bool fuse = (v->variant == 0 || (v->variant >= 4 && v->variant <= 8)) && v->cfg.dim_x % 4 == 0;
     int rc = TSDF_OK;
     for (int k = 0; k < n_frames && rc == TSDF_OK;) {
         const int n = fuse ? std::min(frames_per_launch(v), n_frames - k) : 1;
@@ -592,6 +642,8 @@ int tsdf_destroy(tsdf_volume *v)
     if (v->d_bp) (void)hipFree(v->d_bp);
     if (v->d_scratch) (void)hipFree(v->d_scratch);
     if (v->d_flags) (void)hipFree(v->d_flags);
+    if (v->d_tiles) (void)hipFree(v->d_tiles);
+    if (v->d_shortcut_stats) (void)hipFree(v->d_shortcut_stats);
     if (v->d_tsdf) (void)hipFree(v->d_tsdf);
     if (v->d_weight) (void)hipFree(v->d_weight);
     if (v->own_stream) (void)hipStreamDestroy(v->own_stream);
@@ -800,10 +852,29 @@ int tsdf_device_ptrs(tsdf_volume *v, float **tsdf_dev, float **weight_dev)
 
 int64_t tsdf_slab_voxels(const tsdf_volume *v) { return v ? v->n_vox : 0; }
 
+int tsdf_shortcut_stats(tsdf_volume *v, int32_t enable, uint64_t counts_out[3])
+{
+    if (!v) return fail(TSDF_ERR_INVALID, "tsdf_shortcut_stats: NULL handle");
+    int rc = bind_device(v);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(v->stream));
+    if (counts_out) {
+        unsigned int h[3] = {0, 0, 0};
+        if (v->d_shortcut_stats) HIP_TRY(hipMemcpy(h, v->d_shortcut_stats, sizeof h, hipMemcpyDeviceToHost));
+        for (int i = 0; i < 3; ++i) counts_out[i] = h[i];
+    }
+    if (enable && !v->d_shortcut_stats) HIP_TRY(hipMalloc((void **)&v->d_shortcut_stats, 3 * sizeof(unsigned int)));
+    if (v->d_shortcut_stats) {
+        if (enable) HIP_TRY(hipMemset(v->d_shortcut_stats, 0, 3 * sizeof(unsigned int)));
+        else { (void)hipFree(v->d_shortcut_stats); v->d_shortcut_stats = nullptr; }
+    }
+    return TSDF_OK;
+}
+
 int32_t tsdf_frames_per_launch(const tsdf_volume *v)
 {
     if (!v) return 0;
-    const bool fuse = (v->variant == 0 || (v->variant >= 4 && v->variant <= 6)) && v->cfg.dim_x % 4 == 0;
+    const bool fuse = (v->variant == 0 || (v->variant >= 4 && v->variant <= 8)) && v->cfg.dim_x % 4 == 0;
     return fuse ? frames_per_launch(v) : 1;
 }
 
@@ -843,7 +914,7 @@ int tsdf_set_kernel_variant(tsdf_volume *v, int32_t variant)
     if (!v) return fail(TSDF_ERR_INVALID, "tsdf_set_kernel_variant: NULL handle");
     const int c = (variant - 32) & 15;
     const bool sum_ok = (variant >= 32 && variant < 112 && c < 12 && ((c >> 1) & 1)) || variant == 115 || variant == 119;
-    if (!(variant >= 0 && variant <= 6) && !(variant >= 16 && variant < 28) && !sum_ok)
+    if (!((variant >= 0 && variant <= 6) || variant == 8) && !(variant >= 16 && variant < 28) && !sum_ok)
         return fail(TSDF_ERR_INVALID, "tsdf_set_kernel_variant: unknown variant %d", variant);
     v->variant = variant;
     return TSDF_OK;

@@ -57,6 +57,13 @@ struct IntegrateParams {
     // |camera z| below which a lane's patch counts as "near the camera plane": far above the rounding
     // error of cz over this slab (host: 1e-5 x the bound on |cz|), far above TSDF_FAST_D_MIN
     float cz_margin;
+    // Depth tile summaries (tsdf_multiframe.hip.h, classify_patch): tiles per image row / column, the half-width
+    // in pixels by which a projected patch is widened (host: 1.5 + the projection's error bound), and optional
+    // counters {no claim, every voxel updated with dist = 1, no voxel updated} per wavefront-frame (null = off).
+    int tiles_w, tiles_h;
+    float px_margin_u, px_margin_v;
+    unsigned int *shortcut_stats;
+    float cz_short, cz_pad;   // per pose; copied into FramePose (see there)
 };
 
 // Terms of the camera-frame point that do not depend on x (shared by a lane's voxels).

@@ -30,7 +30,138 @@ struct FramePose {
     // per-voxel label fusion of the same frame (LABELS kernels; both null = no label evidence in this frame)
     const uint16_t *label_im;
     const float *score_im;
+    // depth tile summary of this frame (classify_patch; null = none, e.g. a masked frame) and the camera-frame z
+    // below which a patch is too close to the camera plane for its projected bounding box to be trusted
+    const float2 *tiles;
+    float cz_short;   // host: max(B / 64, error bound / 3.2e-5), B = bound on the camera-frame coordinates of the slab
+    float cz_pad;     // host: >= twice the bound on |exact-path cz - affine cz| (and on the corner arithmetic's error)
 };
+
+// ---- depth tile summaries ---------------------------------------------------------------------------------
+// Per 16 x 16 pixel tile of a depth frame: x = the smallest depth if EVERY pixel of the tile passes the
+// reference's depth-range test (0 < d <= max_depth, ref: src/tsdf.cu:46), else -inf; y = the largest depth among
+// the pixels that pass it, -inf if none does.  A NaN anywhere in the tile (NaN passes the reference's tests and
+// updates the voxel) makes the tile claim nothing: (-inf, +inf).
+constexpr int kTile = 16;
+
+struct TileSummaryParams {
+    const float *depth[kMaxFramesPerLaunch];
+    float2 *tiles;          // n_frames x tiles_h x tiles_w
+    int H, W, tiles_w, tiles_h;
+    float max_depth;
+};
+
+__global__ __launch_bounds__(64) void depth_tile_summary(TileSummaryParams tp)
+{
+    const int tile = blockIdx.x, f = blockIdx.y;
+    const int ty = tile / tp.tiles_w, tx = tile - ty * tp.tiles_w;
+    const int lane = threadIdx.x;
+    const int py = ty * kTile + (lane >> 2), px0 = tx * kTile + (lane & 3) * 4;
+    const float *d = tp.depth[f];
+    const float inf = __builtin_inff();
+    float mn = inf, mx = -inf;
+    bool all_valid = true, nan = false;
+    if (py < tp.H) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int px = px0 + i;
+            if (px < tp.W) {
+                const float v = d[(size_t)py * tp.W + px];
+                nan |= v != v;
+                const bool valid = (v > 0.0f) & (v <= tp.max_depth);
+                all_valid &= valid;
+                if (valid) { mn = fminf(mn, v); mx = fmaxf(mx, v); }
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, off));
+        mx = fmaxf(mx, __shfl_xor(mx, off));
+    }
+    const bool any_nan = __ballot(nan) != 0ull, every_valid = __ballot(!all_valid) == 0ull;
+    if (lane == 0) {
+        float2 out;
+        out.x = (every_valid && !any_nan) ? mn : -inf;
+        out.y = any_nan ? inf : mx;
+        tp.tiles[((size_t)f * tp.tiles_h + ty) * tp.tiles_w + tx] = out;
+    }
+}
+
+// What one frame does to ALL voxels of a wavefront's patch -- the rectangle x in [xa, xb], y in [ya, yb] of slice
+// gz that contains them -- decided from the patch's corners and the depth tile summaries, without projecting a
+// single voxel:
+//   1  every voxel is updated with dist = 1: all of them project inside the image, onto tiles whose pixels are
+//      all valid and at least trunc deeper than the farthest corner;
+//   2  no voxel is updated: the patch misses the image, or every valid pixel it can reach is more than trunc
+//      nearer than the nearest corner (the voxels lie behind the surface, ref: src/tsdf.cu:49);
+//   0  no claim -- the per-voxel path decides.
+// Why the claims are exact: the patch is planar and, when all corners are in front of the
+// camera, projects into the convex hull of its projected corners; camera-frame z is affine over it, so its
+// extremes are at the corners.  The corners are projected with ordinary fp32 arithmetic; the widening of the
+// pixel box (px_margin: 1.5 px + the host's bound on that arithmetic's and the per-voxel path's error, valid for
+// cz >= cz_short) and cz_pad on the z bounds (twice the host's error bound on cz) cover the difference to the exact
+// per-voxel values, and rounding is monotone: d - cz >= trunc in the reals implies RN(d - cz) >= trunc.  Any NaN or
+// infinity in the corner arithmetic fails a comparison and returns 0.
+__device__ __forceinline__ int classify_patch(const IntegrateParams &p, const FramePose &q, const int xa, const int xb,
+                                              const int ya, const int yb, const int gz)
+{
+    const float dz = (p.oz + (float)gz * p.vs) - q.tz;
+    const float dxa = (p.ox + (float)xa * p.vs) - q.tx, dxb = (p.ox + (float)xb * p.vs) - q.tx;
+    const float dya = (p.oy + (float)ya * p.vs) - q.ty;
+    const float zx = q.rx2 * dz, zy = q.ry2 * dz, zz = q.rz2 * dz;
+    float umin = __builtin_inff(), umax = -__builtin_inff(), vmin = umin, vmax = umax, czmin = umin, czmax = umax;
+    auto corner = [&](const float dx, const float dy) {
+        const float cx = q.rx0 * dx + q.rx1 * dy + zx;
+        const float cy = q.ry0 * dx + q.ry1 * dy + zy;
+        const float cz = q.rz0 * dx + q.rz1 * dy + zz;
+        const float inv = __builtin_amdgcn_rcpf(cz);
+        const float u = p.fx * (cx * inv) + p.cx, v = p.fy * (cy * inv) + p.cy;
+        umin = fminf(umin, u); umax = fmaxf(umax, u);
+        vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
+        czmin = fminf(czmin, cz); czmax = fmaxf(czmax, cz);
+        return (u == u) & (v == v);     // fmin/fmax drop a NaN operand: keep it visible
+    };
+    bool finite = corner(dxa, dya) & corner(dxb, dya);
+    if (ya != yb) {   // wave-uniform: a chunk of the flat mapping that spans rows
+        const float dyb = (p.oy + (float)yb * p.vs) - q.ty;
+        finite &= corner(dxa, dyb) & corner(dxb, dyb);
+    }
+    if (!(finite & (czmin > q.cz_short) & (czmax < 3.0e38f))) return 0;
+    // pixel box that contains the rounded pixel of every voxel of the patch
+    const float u0 = umin - p.px_margin_u, u1 = umax + p.px_margin_u;
+    const float v0 = vmin - p.px_margin_v, v1 = vmax + p.px_margin_v;
+    if (!(u1 >= 0.0f) | !(v1 >= 0.0f) | !(u0 <= (float)(p.W - 1)) | !(v0 <= (float)(p.H - 1))) {
+        // the box misses the image (or a bound is NaN, which the finite test above excludes)
+        return 2;
+    }
+    const bool inside = (u0 >= 0.0f) & (v0 >= 0.0f) & (u1 <= (float)(p.W - 1)) & (v1 <= (float)(p.H - 1));
+    const float cu0 = fmaxf(u0, 0.0f), cv0 = fmaxf(v0, 0.0f);
+    const float cu1 = fminf(u1, (float)(p.W - 1)), cv1 = fminf(v1, (float)(p.H - 1));
+    const int tx0 = (int)(cu0 * (1.0f / kTile)), tx1 = (int)(cu1 * (1.0f / kTile));
+    const int ty0 = (int)(cv0 * (1.0f / kTile)), ty1 = (int)(cv1 * (1.0f / kTile));
+    const int tw = tx1 - tx0 + 1, th = ty1 - ty0 + 1;
+    // lane = (column, row) of a 16 x 4 block of tiles; at most 4 blocks per patch, else no claim
+    const int nbx = (tw + 15) >> 4, nby = (th + 3) >> 2;
+    if (nbx * nby > 4) return 0;
+    const float thr_free = (czmax + q.cz_pad) + p.trunc;    // every pixel at least this deep: dist = 1 everywhere
+    const float thr_skip = (czmin - q.cz_pad) - p.trunc;    // every valid pixel at most this deep: nothing updated
+    const int lx = threadIdx.x & 15, ly = (threadIdx.x >> 4) & 3;
+    bool not_free = false, not_skip = false;
+    for (int by = 0; by < nby; ++by) {
+        for (int bx = 0; bx < nbx; ++bx) {
+            const int tx = tx0 + bx * 16 + lx, ty = ty0 + by * 4 + ly;
+            if (tx <= tx1 && ty <= ty1) {
+                const float2 t = q.tiles[ty * p.tiles_w + tx];
+                not_free |= !(t.x >= thr_free);
+                not_skip |= !(t.y <= thr_skip);
+            }
+        }
+    }
+    if (inside && __ballot(not_free) == 0ull) return 1;
+    if (__ballot(not_skip) == 0ull) return 2;
+    return 0;
+}
 
 // Slab arrays of the per-voxel label state (tsdf_labels.hip.h), for the LABELS kernels.
 struct LabelState {
@@ -65,11 +196,14 @@ struct MultiParamsInline {
 // pass, from the projection and depth tests Integrate has just made -- the separate label sweep recomputes both.
 // MASKS = false: the host promises that no frame of the launch carries an instance mask, and the kernel holds
 // no mask bytes, defaults or null tests (2 of 44 VALU instructions per voxel-frame).
-template <int R, bool NT, bool FLAT, bool LABELS = false, bool MASKS = true>
+// SHORT: frames that come with depth tile summaries are first classified per wavefront (classify_patch): all voxels
+// updated with dist = 1, or none updated, without projecting any of them.
+template <int R, bool NT, bool FLAT, bool LABELS = false, bool MASKS = true, bool SHORT = false>
 __device__ __forceinline__ void multi_body(const IntegrateParams &p, const FramePose *__restrict__ frames,
                                            const int n_frames, const int b0, const int b1, const int lz,
                                            const LabelState ls = LabelState())
 {
+    static_assert(!SHORT || R == 1, "patch classification is written for one row per lane");
     static_assert(!LABELS || R == 1, "label fusion rides on the one-row kernel");
     static_assert(!FLAT || R == 1, "the flat mapping handles one quad per lane");
     int xg, gy0;
@@ -90,6 +224,25 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
         flag0 = ((size_t)lz * p.dim_y + gy0) * (size_t)p.nseg + b0;
     }
     const int gz = p.z_begin + lz;
+
+    // (SHORT) the rectangle of this slice that contains the wavefront's voxels, wave-uniform
+    int pxa = 0, pxb = 0, pya = 0, pyb = 0;
+    if constexpr (SHORT) {
+        if constexpr (FLAT) {
+            const int i0 = (b0 * 4 + threadIdx.y) * 256;
+            const int i1 = min(i0 + 255, p.quads_per_slice * 4 - 1);
+            pya = i0 / p.dim_x;
+            pyb = i1 / p.dim_x;
+            pxa = pya == pyb ? i0 - pya * p.dim_x : 0;
+            pxb = pya == pyb ? i1 - pyb * p.dim_x : p.dim_x - 1;
+        } else {
+            pxa = b0 * 256;
+            pxb = min(pxa + 255, p.dim_x - 1);
+            pya = pyb = gy0;
+        }
+        pxa = __builtin_amdgcn_readfirstlane(pxa); pxb = __builtin_amdgcn_readfirstlane(pxb);
+        pya = __builtin_amdgcn_readfirstlane(pya); pyb = __builtin_amdgcn_readfirstlane(pyb);
+    }
 
     // ---- voxel state held in registers across the frames ----------------------------------------
     uint32_t fl[R];
@@ -119,6 +272,29 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
     for (int f = 0; f < n_frames; ++f) {
         const FramePose q = frames[f];   // wave-uniform address: scalar loads
 
+        float diff[R][4];
+        bool upd[R][4], rowany[R], bandr[R];
+        bool any = false, band = false;
+        bool all_free = false;
+        if constexpr (SHORT) {
+            if (q.tiles != nullptr) {
+                const int cls = classify_patch(p, q, pxa, pxb, pya, pyb, gz);
+                if (p.shortcut_stats != nullptr && (threadIdx.x & 63) == 0) atomicAdd(p.shortcut_stats + cls, 1u);
+                if (cls == 2) continue;
+                all_free = cls == 1;
+            }
+        }
+        if (all_free) {
+            // every voxel of the wavefront: valid pixel, diff >= trunc (dist = 1 below), none in the band
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                rowany[r] = true;
+                bandr[r] = false;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { upd[r][j] = true; diff[r][j] = p.trunc; }
+            }
+            any = true;
+        } else {
         // ---- geometry of frame f (ref: src/tsdf.cu:33-43) ------------------------------------------
         float ax[4], ay[4], az[4];
 #pragma unroll
@@ -212,9 +388,6 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
         }
 
         // ---- depth tests (ref: src/tsdf.cu:46-49) ----------------------------------------------------
-        float diff[R][4];
-        bool upd[R][4], rowany[R], bandr[R];
-        bool any = false, band = false;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             rowany[r] = false;
@@ -273,6 +446,8 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
                 }
             }
         }
+
+        }   // !all_free (a wavefront classified as free space has no band voxel: no label evidence either)
 
         // ---- first touch: bring the quads in -------------------------------------------------------
 #pragma unroll
@@ -359,7 +534,7 @@ __global__ __launch_bounds__(256, R == 2 ? 6 : 1) void integrate_multi(MultiPara
     multi_body<R, NT, FLAT>(mp.common, mp.frames, mp.n_frames, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
-template <int R, bool NT, bool FLAT, bool LABELS = false, bool MASKS = true>
+template <int R, bool NT, bool FLAT, bool LABELS = false, bool MASKS = true, bool SHORT = false>
 __global__ __launch_bounds__(256, R == 2 ? 6 : 1) void integrate_multi_inline(MultiParamsInline mp)
 {
     // the single by-value parameter starts the kernarg segment (offset 0)
@@ -367,8 +542,8 @@ __global__ __launch_bounds__(256, R == 2 ? 6 : 1) void integrate_multi_inline(Mu
     kernarg_ptr base = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
     typedef const FramePose __attribute__((address_space(4))) *frames_ptr;
     frames_ptr frames = (frames_ptr)(base + offsetof(MultiParamsInline, frames));
-    multi_body<R, NT, FLAT, LABELS, MASKS>(mp.common, (const FramePose *)frames, mp.n_frames, blockIdx.x, blockIdx.y,
-                                           blockIdx.z, mp.labels);
+    multi_body<R, NT, FLAT, LABELS, MASKS, SHORT>(mp.common, (const FramePose *)frames, mp.n_frames, blockIdx.x,
+                                                  blockIdx.y, blockIdx.z, mp.labels);
 }
 
 // Experiment (variant 5): XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs, so

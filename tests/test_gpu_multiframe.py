@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("dims", [(256, 42, 30), (200, 42, 30), (36, 20, 12)])   # row mapping, flat, flat + partial chunk
-@pytest.mark.parametrize("variant", [0, 4, 3, 5])
+@pytest.mark.parametrize("variant", [0, 4, 3, 5, 8])
 @pytest.mark.parametrize("n_frames", [1, 3, 4, 9, 32, 33, 70])   # kMaxFramesPerLaunch = 32: one full pass, +1, 2 full + 6
 def test_fused_frames_equal_sequential_and_oracle(cuda, oracle, n_frames, variant, dims):
     if n_frames > 9 and (variant != 0 or dims[0] == 36):
@@ -52,3 +52,35 @@ def test_fused_frames_equal_sequential_and_oracle(cuda, oracle, n_frames, varian
         t, w = vol.download()
     assert ref_w.max() >= 2 or n_frames == 1
     assert np.array_equal(w, ref_w) and np.array_equal(t.view(np.uint32), ref_t.view(np.uint32))
+
+
+def test_patch_classification_experiment_is_exact_and_fires(cuda, oracle):
+    """Variant 8: wavefronts whose patch the depth tile summaries decide (all free space / nothing to update) never
+    project a voxel.  Planes at depths around cz + trunc (where the free-space claim must stop), a frame the volume
+    misses entirely and a frame with invalid pixels: bit-exact against the oracle, and every class is taken."""
+    dims, vs = (256, 64, 40), 0.002      # a 256-voxel row fits the image at this range
+    origin = synth.surf_volume(256, vs, 0.7)
+    cfg = capi.make_config(dims, vs, origin)
+    far = origin[2] + dims[2] * vs
+    depths = [np.full((480, 640), far + 0.5, np.float32),                      # everything free space
+              np.full((480, 640), far + cfg.trunc_margin * 1.0001, np.float32),  # the far slices just outside the claim
+              np.full((480, 640), far - 0.03, np.float32),                     # band inside the volume
+              np.full((480, 640), origin[2] - 0.2, np.float32),                # surface in front of the volume: nothing updated
+              np.full((480, 640), far + 0.5, np.float32)]
+    depths[4][100:300, 200:400] = 0.0                                          # invalid pixels in the middle
+    poses = [synth.identity_pose(), synth.make_pose(synth.rot_z(0.05), [0.01, 0.0, 0.0]), synth.identity_pose(),
+             synth.identity_pose(), synth.make_pose(synth.rot_y(0.03), [0.0, 0.01, 0.0]),
+             synth.make_pose(np.eye(3), [5.0, 0.0, 0.0])]                        # the volume is out of view
+    depths.append(depths[0])
+    ref_t, ref_w = oracle.init_grid(dims)
+    for d, p in zip(depths, poses):
+        oracle.integrate(cfg.cam_K, p, d, dims, origin, vs, cfg.trunc_margin, ref_t, ref_w)
+    keep = [cuda.from_numpy(d).cuda() for d in depths]
+    with capi.Volume(cfg) as vol:
+        vol.set_kernel_variant(8)
+        vol.shortcut_stats(True)
+        vol.integrate_frames_device([d.data_ptr() for d in keep], np.stack(poses))
+        per_voxel, free, skipped = vol.shortcut_stats(False)
+        t, w = vol.download()
+    assert np.array_equal(w, ref_w) and np.array_equal(t.view(np.uint32), ref_t.view(np.uint32))
+    assert per_voxel > 0 and free > 0 and skipped > 0 and per_voxel + free + skipped == 6 * dims[1] * dims[2]
