@@ -283,7 +283,7 @@ def main():
         # the figure exceeds the HBM peak; "physical" prices the same launches by the bytes that really move.
         "roofline": {"bound": "hbm", "achieved": round(achieved_survey, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved_survey / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "kernel": "tsdfk::integrate_multi_inline<1,true,false,false,false>" if fused else
+                     "kernel": "tsdfk::integrate_multi_inline<1,true,false,false,false,false>" if fused else
                                ("tsdfk::integrate_tile<2,true,true,false,true,false,true>" if v == 3 else f"variant {v}"),
                      "frames_per_launch": fpl, "launches": launches,
                      "kernel_ms": round(kernel_ms, 5),
