@@ -213,11 +213,11 @@ def main():
     # beside it, as is the plain streaming variant in which those 16 B really move.
     H, W = depth.shape
     v = args.variant
-    fused = v in (0, 4, 5)
+    fused = v in (0, 4, 5, 8)
     fpl = vol.frames_per_launch if fused else 1
     full, rem = divmod(args.steps, fpl)          # K steps = `full` launches of fpl frames + one of `rem`
     launches = full + (1 if rem else 0)
-    has_summary = v in (0, 3, 4, 5) or 32 <= v < 64 or 80 <= v < 96 or v >= 112
+    has_summary = v in (0, 3, 4, 5, 8) or 32 <= v < 64 or 80 <= v < 96 or v >= 112
     has_elide = has_summary or v in (18, 19, 22, 23, 26, 27) or v >= 64
     flag_bytes = 4.0 * n_slab / 256.0 if has_summary else 0.0
 

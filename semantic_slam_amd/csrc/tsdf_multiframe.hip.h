@@ -44,12 +44,19 @@ struct FramePose {
 // updates the voxel) makes the tile claim nothing: (-inf, +inf).
 constexpr int kTile = 16;
 
+// On top of the tiles a 2-D sparse table gives the same two quantities for ANY rectangle of tiles in four loads:
+// level (i, j) holds, at (ty, tx), the combination over the 2^i x 2^j tiles starting there (min of the x's, max of
+// the y's); a rectangle of w x h tiles is the union of four overlapping power-of-two blocks of level
+// (floor(log2 h), floor(log2 w)).  Layout per frame: [level i][level j][ty][tx], levels = floor(log2(dim)) + 1.
 struct TileSummaryParams {
     const float *depth[kMaxFramesPerLaunch];
-    float2 *tiles;          // n_frames x tiles_h x tiles_w
+    float2 *tiles;          // n_frames tables
     int H, W, tiles_w, tiles_h;
     float max_depth;
 };
+
+__device__ __forceinline__ int tile_levels(int n) { return 32 - __clz(n); }   // floor(log2 n) + 1, n >= 1
+__device__ __forceinline__ size_t tile_table_elems(int tw, int th) { return (size_t)tile_levels(tw) * tile_levels(th) * tw * th; }
 
 __global__ __launch_bounds__(64) void depth_tile_summary(TileSummaryParams tp)
 {
@@ -84,33 +91,71 @@ __global__ __launch_bounds__(64) void depth_tile_summary(TileSummaryParams tp)
         float2 out;
         out.x = (every_valid && !any_nan) ? mn : -inf;
         out.y = any_nan ? inf : mx;
-        tp.tiles[((size_t)f * tp.tiles_h + ty) * tp.tiles_w + tx] = out;
+        tp.tiles[(size_t)f * tile_table_elems(tp.tiles_w, tp.tiles_h) + (size_t)ty * tp.tiles_w + tx] = out;
+    }
+}
+
+// One workgroup per frame builds the upper levels from level (0, 0): first along x, then along y.
+__global__ __launch_bounds__(256) void tile_sparse_table(float2 *tables, int tw, int th)
+{
+    const int lj = tile_levels(tw), li = tile_levels(th), n = tw * th;
+    float2 *T = tables + (size_t)blockIdx.x * tile_table_elems(tw, th);
+    auto level = [&](int i, int j) { return T + (size_t)(i * lj + j) * n; };
+    for (int j = 1; j < lj; ++j) {
+        __syncthreads();
+        const float2 *src = level(0, j - 1);
+        float2 *dst = level(0, j);
+        const int step = 1 << (j - 1);
+        for (int k = threadIdx.x; k < n; k += blockDim.x) {
+            const int ty = k / tw, tx = k - ty * tw;
+            const float2 a = src[k], b = src[ty * tw + min(tx + step, tw - 1)];
+            dst[k] = make_float2(fminf(a.x, b.x), fmaxf(a.y, b.y));
+        }
+    }
+    for (int i = 1; i < li; ++i) {
+        __syncthreads();
+        const int step = 1 << (i - 1);
+        for (int j = 0; j < lj; ++j) {
+            const float2 *src = level(i - 1, j);
+            float2 *dst = level(i, j);
+            for (int k = threadIdx.x; k < n; k += blockDim.x) {
+                const int ty = k / tw, tx = k - ty * tw;
+                const float2 a = src[k], b = src[min(ty + step, th - 1) * tw + tx];
+                dst[k] = make_float2(fminf(a.x, b.x), fmaxf(a.y, b.y));
+            }
+        }
     }
 }
 
 // What one frame does to ALL voxels of a wavefront's patch -- the rectangle x in [xa, xb], y in [ya, yb] of slice
-// gz that contains them -- decided from the patch's corners and the depth tile summaries, without projecting a
+// gz that contains them -- decided from the patch's corners and the depth tile tables, without projecting a
 // single voxel:
 //   1  every voxel is updated with dist = 1: all of them project inside the image, onto tiles whose pixels are
 //      all valid and at least trunc deeper than the farthest corner;
 //   2  no voxel is updated: the patch misses the image, or every valid pixel it can reach is more than trunc
 //      nearer than the nearest corner (the voxels lie behind the surface, ref: src/tsdf.cu:49);
 //   0  no claim -- the per-voxel path decides.
+// Evaluated once per workgroup in the kernel prologue with ONE LANE PER FRAME of the launch, so the frame loop only
+// tests a bit.
 // Why the claims are exact: the patch is planar and, when all corners are in front of the
 // camera, projects into the convex hull of its projected corners; camera-frame z is affine over it, so its
 // extremes are at the corners.  The corners are projected with ordinary fp32 arithmetic; the widening of the
 // pixel box (px_margin: 1.5 px + the host's bound on that arithmetic's and the per-voxel path's error, valid for
 // cz >= cz_short) and cz_pad on the z bounds (twice the host's error bound on cz) cover the difference to the exact
-// per-voxel values, and rounding is monotone: d - cz >= trunc in the reals implies RN(d - cz) >= trunc.  Any NaN or
-// infinity in the corner arithmetic fails a comparison and returns 0.
-__device__ __forceinline__ int classify_patch(const IntegrateParams &p, const FramePose &q, const int xa, const int xb,
-                                              const int ya, const int yb, const int gz)
+// per-voxel values, and rounding is monotone: d - cz >= trunc in the reals implies RN(d - cz) >= trunc.  A NaN or an
+// infinity in the corner arithmetic fails a comparison and yields 0.
+__device__ __forceinline__ int classify_patch(const IntegrateParams &p, const FramePose *__restrict__ qp, const int xa,
+                                              const int xb, const int ya, const int yb, const int gz)
 {
+    const FramePose q = *qp;      // this lane's frame
+    if (q.tiles == nullptr) return 0;
     const float dz = (p.oz + (float)gz * p.vs) - q.tz;
     const float dxa = (p.ox + (float)xa * p.vs) - q.tx, dxb = (p.ox + (float)xb * p.vs) - q.tx;
-    const float dya = (p.oy + (float)ya * p.vs) - q.ty;
+    const float dya = (p.oy + (float)ya * p.vs) - q.ty, dyb = (p.oy + (float)yb * p.vs) - q.ty;
     const float zx = q.rx2 * dz, zy = q.ry2 * dz, zz = q.rz2 * dz;
-    float umin = __builtin_inff(), umax = -__builtin_inff(), vmin = umin, vmax = umax, czmin = umin, czmax = umax;
+    const float inf = __builtin_inff();
+    float umin = inf, umax = -inf, vmin = inf, vmax = -inf, czmin = inf, czmax = -inf;
+    bool finite = true;
     auto corner = [&](const float dx, const float dy) {
         const float cx = q.rx0 * dx + q.rx1 * dy + zx;
         const float cy = q.ry0 * dx + q.ry1 * dy + zy;
@@ -120,46 +165,32 @@ __device__ __forceinline__ int classify_patch(const IntegrateParams &p, const Fr
         umin = fminf(umin, u); umax = fmaxf(umax, u);
         vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
         czmin = fminf(czmin, cz); czmax = fmaxf(czmax, cz);
-        return (u == u) & (v == v);     // fmin/fmax drop a NaN operand: keep it visible
+        finite &= (u == u) & (v == v) & (cz == cz);     // fmin/fmax drop a NaN operand: keep it visible
     };
-    bool finite = corner(dxa, dya) & corner(dxb, dya);
-    if (ya != yb) {   // wave-uniform: a chunk of the flat mapping that spans rows
-        const float dyb = (p.oy + (float)yb * p.vs) - q.ty;
-        finite &= corner(dxa, dyb) & corner(dxb, dyb);
-    }
+    corner(dxa, dya); corner(dxb, dya);
+    corner(dxa, dyb); corner(dxb, dyb);   // the same two again when ya == yb
     if (!(finite & (czmin > q.cz_short) & (czmax < 3.0e38f))) return 0;
     // pixel box that contains the rounded pixel of every voxel of the patch
     const float u0 = umin - p.px_margin_u, u1 = umax + p.px_margin_u;
     const float v0 = vmin - p.px_margin_v, v1 = vmax + p.px_margin_v;
-    if (!(u1 >= 0.0f) | !(v1 >= 0.0f) | !(u0 <= (float)(p.W - 1)) | !(v0 <= (float)(p.H - 1))) {
-        // the box misses the image (or a bound is NaN, which the finite test above excludes)
-        return 2;
-    }
-    const bool inside = (u0 >= 0.0f) & (v0 >= 0.0f) & (u1 <= (float)(p.W - 1)) & (v1 <= (float)(p.H - 1));
-    const float cu0 = fmaxf(u0, 0.0f), cv0 = fmaxf(v0, 0.0f);
-    const float cu1 = fminf(u1, (float)(p.W - 1)), cv1 = fminf(v1, (float)(p.H - 1));
-    const int tx0 = (int)(cu0 * (1.0f / kTile)), tx1 = (int)(cu1 * (1.0f / kTile));
-    const int ty0 = (int)(cv0 * (1.0f / kTile)), ty1 = (int)(cv1 * (1.0f / kTile));
-    const int tw = tx1 - tx0 + 1, th = ty1 - ty0 + 1;
-    // lane = (column, row) of a 16 x 4 block of tiles; at most 4 blocks per patch, else no claim
-    const int nbx = (tw + 15) >> 4, nby = (th + 3) >> 2;
-    if (nbx * nby > 4) return 0;
+    const float wmax = (float)(p.W - 1), hmax = (float)(p.H - 1);
+    if (!(u1 >= 0.0f) | !(v1 >= 0.0f) | !(u0 <= wmax) | !(v0 <= hmax)) return 2;   // the box misses the image
+    const bool inside = (u0 >= 0.0f) & (v0 >= 0.0f) & (u1 <= wmax) & (v1 <= hmax);
+    const int tx0 = (int)(fmaxf(u0, 0.0f) * (1.0f / kTile)), tx1 = (int)(fminf(u1, wmax) * (1.0f / kTile));
+    const int ty0 = (int)(fmaxf(v0, 0.0f) * (1.0f / kTile)), ty1 = (int)(fminf(v1, hmax) * (1.0f / kTile));
+    // range query: four overlapping power-of-two blocks of level (ky, kx)
+    const int kx = 31 - __clz(tx1 - tx0 + 1), ky = 31 - __clz(ty1 - ty0 + 1);
+    const int n = p.tiles_w * p.tiles_h;
+    const float2 *L = q.tiles + (size_t)(ky * tile_levels(p.tiles_w) + kx) * n;
+    const int xb2 = tx1 - (1 << kx) + 1, yb2 = ty1 - (1 << ky) + 1;
+    const float2 a = L[ty0 * p.tiles_w + tx0], b = L[ty0 * p.tiles_w + xb2];
+    const float2 c = L[yb2 * p.tiles_w + tx0], d = L[yb2 * p.tiles_w + xb2];
+    const float dmin = fminf(fminf(a.x, b.x), fminf(c.x, d.x));   // -inf unless every pixel of the box is valid
+    const float dmax = fmaxf(fmaxf(a.y, b.y), fmaxf(c.y, d.y));   // the deepest valid pixel of the box
     const float thr_free = (czmax + q.cz_pad) + p.trunc;    // every pixel at least this deep: dist = 1 everywhere
     const float thr_skip = (czmin - q.cz_pad) - p.trunc;    // every valid pixel at most this deep: nothing updated
-    const int lx = threadIdx.x & 15, ly = (threadIdx.x >> 4) & 3;
-    bool not_free = false, not_skip = false;
-    for (int by = 0; by < nby; ++by) {
-        for (int bx = 0; bx < nbx; ++bx) {
-            const int tx = tx0 + bx * 16 + lx, ty = ty0 + by * 4 + ly;
-            if (tx <= tx1 && ty <= ty1) {
-                const float2 t = q.tiles[ty * p.tiles_w + tx];
-                not_free |= !(t.x >= thr_free);
-                not_skip |= !(t.y <= thr_skip);
-            }
-        }
-    }
-    if (inside && __ballot(not_free) == 0ull) return 1;
-    if (__ballot(not_skip) == 0ull) return 2;
+    if (inside & (dmin >= thr_free)) return 1;
+    if (dmax <= thr_skip) return 2;
     return 0;
 }
 
@@ -196,12 +227,13 @@ struct MultiParamsInline {
 // pass, from the projection and depth tests Integrate has just made -- the separate label sweep recomputes both.
 // MASKS = false: the host promises that no frame of the launch carries an instance mask, and the kernel holds
 // no mask bytes, defaults or null tests (2 of 44 VALU instructions per voxel-frame).
-// SHORT: frames that come with depth tile summaries are first classified per wavefront (classify_patch): all voxels
-// updated with dist = 1, or none updated, without projecting any of them.
+// SHORT: the frames of the launch that come with depth tile tables are classified per wavefront in the prologue, one
+// lane per frame (classify_patch): all voxels updated with dist = 1, or none updated, without projecting any of them.
 template <int R, bool NT, bool FLAT, bool LABELS = false, bool MASKS = true, bool SHORT = false>
 __device__ __forceinline__ void multi_body(const IntegrateParams &p, const FramePose *__restrict__ frames,
                                            const int n_frames, const int b0, const int b1, const int lz,
-                                           const LabelState ls = LabelState())
+                                           const LabelState ls = LabelState(), const unsigned int free_frames = 0u,
+                                           const unsigned int skip_frames = 0u)
 {
     static_assert(!SHORT || R == 1, "patch classification is written for one row per lane");
     static_assert(!LABELS || R == 1, "label fusion rides on the one-row kernel");
@@ -224,25 +256,6 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
         flag0 = ((size_t)lz * p.dim_y + gy0) * (size_t)p.nseg + b0;
     }
     const int gz = p.z_begin + lz;
-
-    // (SHORT) the rectangle of this slice that contains the wavefront's voxels, wave-uniform
-    int pxa = 0, pxb = 0, pya = 0, pyb = 0;
-    if constexpr (SHORT) {
-        if constexpr (FLAT) {
-            const int i0 = (b0 * 4 + threadIdx.y) * 256;
-            const int i1 = min(i0 + 255, p.quads_per_slice * 4 - 1);
-            pya = i0 / p.dim_x;
-            pyb = i1 / p.dim_x;
-            pxa = pya == pyb ? i0 - pya * p.dim_x : 0;
-            pxb = pya == pyb ? i1 - pyb * p.dim_x : p.dim_x - 1;
-        } else {
-            pxa = b0 * 256;
-            pxb = min(pxa + 255, p.dim_x - 1);
-            pya = pyb = gy0;
-        }
-        pxa = __builtin_amdgcn_readfirstlane(pxa); pxb = __builtin_amdgcn_readfirstlane(pxb);
-        pya = __builtin_amdgcn_readfirstlane(pya); pyb = __builtin_amdgcn_readfirstlane(pyb);
-    }
 
     // ---- voxel state held in registers across the frames ----------------------------------------
     uint32_t fl[R];
@@ -267,34 +280,106 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
     const float bz = p.oz + (float)gz * p.vs;
     const v2f F = {p.fx, p.fy}, C = {p.cx, p.cy};
 
+    // What a frame does to the lane's voxels once upd / diff are known (ref: src/tsdf.cu:53-57): the quads are brought in
+    // on first touch and updated in registers.  Shared by the per-voxel path and the classified free-space path.
+    float diff[R][4];
+    bool upd[R][4], rowany[R], bandr[R];
+    bool any = false, band = false;
+    auto apply_frame = [&]() __attribute__((always_inline)) {
+        // ---- first touch: bring the quads in -------------------------------------------------------
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (rowany[r] && !touched[r]) {
+                w4[r] = vol_load<NT>(p.weight + row0 + (size_t)r * p.dim_x);
+                if (!(fl[r] & 1u)) t4[r] = vol_load<NT>(p.tsdf + row0 + (size_t)r * p.dim_x);
+                touched[r] = true;
+            }
+        }
+        float dist[R][4];
+        if (__ballot(band) != 0ull) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dist[r][j] = fminf(1.0f, diff[r][j] / p.trunc);  // ref: :53
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dist[r][j] = 1.0f;
+        }
+
+        // ---- update in registers (ref: src/tsdf.cu:54-57) ----------------------------------------------
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (ones[r] && (fl[r] & 2u) && __ballot(bandr[r]) == 0ull) {
+                // free space (see integrate_tile): the TSDF row stays 1, only the weights move
+                if (upd[r][0]) w4[r].x += 1.0f;
+                if (upd[r][1]) w4[r].y += 1.0f;
+                if (upd[r][2]) w4[r].z += 1.0f;
+                if (upd[r][3]) w4[r].w += 1.0f;
+                continue;
+            }
+            float tv[4] = {t4[r].x, t4[r].y, t4[r].z, t4[r].w};
+            float wv[4] = {w4[r].x, w4[r].y, w4[r].z, w4[r].w};
+            float num[4], wn[4];
+            bool need = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                wn[j] = wv[j] + 1.0f;
+                num[j] = tv[j] * wv[j] + dist[r][j];
+                need |= upd[r][j] && !(num[j] == wn[j] && wn[j] < 3.0e38f && wn[j] > 0.0f);
+            }
+            float nt[4];
+            if (__ballot(rowany[r] && need) != 0ull) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) nt[j] = num[j] / wn[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) nt[j] = 1.0f;
+            }
+            bool changed = false, notone = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float newt = upd[r][j] ? nt[j] : tv[j];
+                changed |= __float_as_uint(newt) != __float_as_uint(tv[j]);
+                notone |= upd[r][j] && __float_as_uint(newt) != 0x3f800000u;
+                tv[j] = newt;
+                wv[j] = upd[r][j] ? wn[j] : wv[j];
+            }
+            t4[r] = make_float4(tv[0], tv[1], tv[2], tv[3]);
+            w4[r] = make_float4(wv[0], wv[1], wv[2], wv[3]);
+            tchanged[r] |= changed;
+            if (__ballot(notone) != 0ull) ones[r] = false;   // for every lane of the wavefront
+        }
+    };
+
     // not unrolled: one frame's temporaries at a time (unrolling interleaves frames: 100 VGPRs)
 #pragma unroll 1
     for (int f = 0; f < n_frames; ++f) {
-        const FramePose q = frames[f];   // wave-uniform address: scalar loads
-
-        float diff[R][4];
-        bool upd[R][4], rowany[R], bandr[R];
-        bool any = false, band = false;
-        bool all_free = false;
         if constexpr (SHORT) {
-            if (q.tiles != nullptr) {
-                const int cls = classify_patch(p, q, pxa, pxb, pya, pyb, gz);
-                if (p.shortcut_stats != nullptr && (threadIdx.x & 63) == 0) atomicAdd(p.shortcut_stats + cls, 1u);
-                if (cls == 2) continue;
-                all_free = cls == 1;
+            const bool skip = (skip_frames >> f) & 1u, all_free = (free_frames >> f) & 1u;
+            if (p.shortcut_stats != nullptr && (threadIdx.x & 63) == 0)
+                atomicAdd(p.shortcut_stats + (skip ? 2 : all_free ? 1 : 0), 1u);
+            if (skip) continue;
+            if (all_free) {
+                // every voxel of the wavefront: valid pixel, diff >= trunc (dist = 1), none in the band
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    rowany[r] = true;
+                    bandr[r] = false;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { upd[r][j] = true; diff[r][j] = p.trunc; }
+                }
+                band = false;
+                apply_frame();
+                continue;
             }
         }
-        if (all_free) {
-            // every voxel of the wavefront: valid pixel, diff >= trunc (dist = 1 below), none in the band
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                rowany[r] = true;
-                bandr[r] = false;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { upd[r][j] = true; diff[r][j] = p.trunc; }
-            }
-            any = true;
-        } else {
+        any = false;
+        band = false;
+        {
+        const FramePose q = frames[f];   // wave-uniform address: scalar loads (not needed by a classified frame)
+
         // ---- geometry of frame f (ref: src/tsdf.cu:33-43) ------------------------------------------
         float ax[4], ay[4], az[4];
 #pragma unroll
@@ -447,73 +532,9 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
             }
         }
 
-        }   // !all_free (a wavefront classified as free space has no band voxel: no label evidence either)
-
-        // ---- first touch: bring the quads in -------------------------------------------------------
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            if (rowany[r] && !touched[r]) {
-                w4[r] = vol_load<NT>(p.weight + row0 + (size_t)r * p.dim_x);
-                if (!(fl[r] & 1u)) t4[r] = vol_load<NT>(p.tsdf + row0 + (size_t)r * p.dim_x);
-                touched[r] = true;
-            }
-        }
-        float dist[R][4];
-        if (__ballot(band) != 0ull) {
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) dist[r][j] = fminf(1.0f, diff[r][j] / p.trunc);  // ref: :53
-        } else {
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) dist[r][j] = 1.0f;
         }
 
-        // ---- update in registers (ref: src/tsdf.cu:54-57) ----------------------------------------------
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            if (ones[r] && (fl[r] & 2u) && __ballot(bandr[r]) == 0ull) {
-                // free space (see integrate_tile): the TSDF row stays 1, only the weights move
-                if (upd[r][0]) w4[r].x += 1.0f;
-                if (upd[r][1]) w4[r].y += 1.0f;
-                if (upd[r][2]) w4[r].z += 1.0f;
-                if (upd[r][3]) w4[r].w += 1.0f;
-                continue;
-            }
-            float tv[4] = {t4[r].x, t4[r].y, t4[r].z, t4[r].w};
-            float wv[4] = {w4[r].x, w4[r].y, w4[r].z, w4[r].w};
-            float num[4], wn[4];
-            bool need = false;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                wn[j] = wv[j] + 1.0f;
-                num[j] = tv[j] * wv[j] + dist[r][j];
-                need |= upd[r][j] && !(num[j] == wn[j] && wn[j] < 3.0e38f && wn[j] > 0.0f);
-            }
-            float nt[4];
-            if (__ballot(rowany[r] && need) != 0ull) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) nt[j] = num[j] / wn[j];
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) nt[j] = 1.0f;
-            }
-            bool changed = false, notone = false;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float newt = upd[r][j] ? nt[j] : tv[j];
-                changed |= __float_as_uint(newt) != __float_as_uint(tv[j]);
-                notone |= upd[r][j] && __float_as_uint(newt) != 0x3f800000u;
-                tv[j] = newt;
-                wv[j] = upd[r][j] ? wn[j] : wv[j];
-            }
-            t4[r] = make_float4(tv[0], tv[1], tv[2], tv[3]);
-            w4[r] = make_float4(wv[0], wv[1], wv[2], wv[3]);
-            tchanged[r] |= changed;
-            if (__ballot(notone) != 0ull) ones[r] = false;   // for every lane of the wavefront
-        }
+        apply_frame();
     }
 
     // ---- write back ------------------------------------------------------------------------------------
@@ -542,8 +563,52 @@ __global__ __launch_bounds__(256, R == 2 ? 6 : 1) void integrate_multi_inline(Mu
     kernarg_ptr base = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
     typedef const FramePose __attribute__((address_space(4))) *frames_ptr;
     frames_ptr frames = (frames_ptr)(base + offsetof(MultiParamsInline, frames));
+    unsigned int free_frames = 0u, skip_frames = 0u;
+    if constexpr (SHORT) {
+        // Patch classification, once per workgroup: its voxels lie in one rectangle of the slice (256 x 4 voxels in
+        // the row mapping, 1024 consecutive voxels in the flat one).  The first wavefront stages the frame blocks in
+        // LDS (coalesced) and classifies one frame per lane; bit f of the two words then tells every wavefront of
+        // the workgroup what frame f does to all of its voxels.
+        __shared__ FramePose s_frames[kMaxFramesPerLaunch];
+        __shared__ unsigned int s_bits[2];
+        static_assert(sizeof(FramePose) % 8 == 0, "staged as 8-byte words");
+        if (threadIdx.y == 0) {
+            const IntegrateParams &p = mp.common;
+            const int lane = threadIdx.x;
+            constexpr int kWords = (int)(sizeof(FramePose) * kMaxFramesPerLaunch / 8);
+            const unsigned long long __attribute__((address_space(4))) *src =
+                (const unsigned long long __attribute__((address_space(4))) *)frames;
+            unsigned long long *dst = reinterpret_cast<unsigned long long *>(s_frames);
+            for (int k = lane; k < kWords; k += 64) dst[k] = src[k];
+            int xa, xb, ya, yb;
+            if constexpr (FLAT) {
+                const int i0 = (int)blockIdx.x * 1024;
+                const int i1 = min(i0 + 1023, p.quads_per_slice * 4 - 1);
+                ya = i0 / p.dim_x;
+                yb = i1 / p.dim_x;
+                xa = ya == yb ? i0 - ya * p.dim_x : 0;
+                xb = ya == yb ? i1 - yb * p.dim_x : p.dim_x - 1;
+            } else {
+                xa = (int)blockIdx.x * 256;
+                xb = min(xa + 255, p.dim_x - 1);
+                ya = (int)blockIdx.y * 4;
+                yb = min(ya + 3, p.dim_y - 1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            int cls = 0;
+            if (lane < mp.n_frames) cls = classify_patch(p, s_frames + lane, xa, xb, ya, yb, p.z_begin + (int)blockIdx.z);
+            const unsigned long long fb = __ballot(cls == 1), sb = __ballot(cls == 2);
+            if (lane == 0) { s_bits[0] = (unsigned int)fb; s_bits[1] = (unsigned int)sb; }
+        }
+        __syncthreads();
+        free_frames = s_bits[0];
+        skip_frames = s_bits[1];
+        free_frames = __builtin_amdgcn_readfirstlane(free_frames);
+        skip_frames = __builtin_amdgcn_readfirstlane(skip_frames);
+    }
     multi_body<R, NT, FLAT, LABELS, MASKS, SHORT>(mp.common, (const FramePose *)frames, mp.n_frames, blockIdx.x,
-                                                  blockIdx.y, blockIdx.z, mp.labels);
+                                                  blockIdx.y, blockIdx.z, mp.labels, free_frames, skip_frames);
 }
 
 // Experiment (variant 5): XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs, so
