@@ -404,7 +404,7 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
             for (int f = 0; f < n && masks_dev; ++f) any_mask = any_mask || masks_dev[f] != nullptr;
             dim3 grid_flat((v->chunks_per_slice + 3) / 4, 1, nz), grid_rows((mi.common.xgroups + 63) / 64, (c.dim_y + 3) / 4, nz);
             // patch classification: frames without masks, tables of at most 4 MiB per frame
-            const bool classify = !any_mask && v->variant == 8 && (int64_t)mi.common.tiles_w * mi.common.tiles_h <= 8192;
+            const bool classify = v->variant == 8 && (int64_t)mi.common.tiles_w * mi.common.tiles_h <= 8192;
             if (classify) {
                 // depth tile tables of the n frames (two small launches), then the kernel that consults them
                 auto levels = [](int n_) { int l = 0; while (n_ > 0) { ++l; n_ >>= 1; } return l; };
@@ -412,7 +412,10 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
                                          mi.common.tiles_w * mi.common.tiles_h;
                 if (!v->d_tiles) HIP_TRY(hipMalloc((void **)&v->d_tiles, tsdfk::kMaxFramesPerLaunch * per_frame * sizeof(float2)));
                 tsdfk::TileSummaryParams tp;
-                for (int f = 0; f < tsdfk::kMaxFramesPerLaunch; ++f) tp.depth[f] = depth_dev[f < n ? f : 0];
+                for (int f = 0; f < tsdfk::kMaxFramesPerLaunch; ++f) {
+                    tp.depth[f] = depth_dev[f < n ? f : 0];
+                    tp.mask[f] = masks_dev ? masks_dev[f < n ? f : 0] : nullptr;
+                }
                 tp.tiles = v->d_tiles;
                 tp.H = c.im_height; tp.W = c.im_width; tp.tiles_w = mi.common.tiles_w; tp.tiles_h = mi.common.tiles_h;
                 tp.max_depth = c.max_depth;
@@ -423,7 +426,11 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
                 for (int f = 0; f < n; ++f) mi.frames[f].tiles = v->d_tiles + (size_t)f * per_frame;
                 for (int f = n; f < tsdfk::kMaxFramesPerLaunch; ++f) mi.frames[f] = mi.frames[0];
             }
-            if (v->flat && any_mask)
+            if (v->flat && any_mask && classify)
+                hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, true, false, true, true>), grid_flat, block, 0, v->stream, mi);
+            else if (!v->flat && any_mask && classify)
+                hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, false, true, true>), grid_rows, block, 0, v->stream, mi);
+            else if (v->flat && any_mask)
                 hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, true, false, true>), grid_flat, block, 0, v->stream, mi);
             else if (v->flat && classify)
                 hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, true, false, false, true>), grid_flat, block, 0, v->stream, mi);

@@ -50,6 +50,8 @@ constexpr int kTile = 16;
 // (floor(log2 h), floor(log2 w)).  Layout per frame: [level i][level j][ty][tx], levels = floor(log2(dim)) + 1.
 struct TileSummaryParams {
     const float *depth[kMaxFramesPerLaunch];
+    const uint8_t *mask[kMaxFramesPerLaunch];   // instance mask of the frame or null: the summary is of depth * (mask / 255),
+                                                // the image Integrate sees (ref: src/Engine.cpp:192-193)
     float2 *tiles;          // n_frames tables
     int H, W, tiles_w, tiles_h;
     float max_depth;
@@ -65,6 +67,7 @@ __global__ __launch_bounds__(64) void depth_tile_summary(TileSummaryParams tp)
     const int lane = threadIdx.x;
     const int py = ty * kTile + (lane >> 2), px0 = tx * kTile + (lane & 3) * 4;
     const float *d = tp.depth[f];
+    const uint8_t *m = tp.mask[f];
     const float inf = __builtin_inff();
     float mn = inf, mx = -inf;
     bool all_valid = true, nan = false;
@@ -73,7 +76,8 @@ __global__ __launch_bounds__(64) void depth_tile_summary(TileSummaryParams tp)
         for (int i = 0; i < 4; ++i) {
             const int px = px0 + i;
             if (px < tp.W) {
-                const float v = d[(size_t)py * tp.W + px];
+                float v = d[(size_t)py * tp.W + px];
+                if (m != nullptr) v = v * (m[(size_t)py * tp.W + px] >= 128 ? 1.0f : 0.0f);   // inf * 0 = NaN, as in the kernel
                 nan |= v != v;
                 const bool valid = (v > 0.0f) & (v <= tp.max_depth);
                 all_valid &= valid;

@@ -84,3 +84,38 @@ def test_patch_classification_experiment_is_exact_and_fires(cuda, oracle):
         t, w = vol.download()
     assert np.array_equal(w, ref_w) and np.array_equal(t.view(np.uint32), ref_t.view(np.uint32))
     assert per_voxel > 0 and free > 0 and skipped > 0 and per_voxel + free + skipped == 6 * dims[1] * dims[2]
+
+
+def test_patch_classification_with_instance_masks(cuda, oracle):
+    """Variant 8 on masked frames: the tile summary is taken of depth x mask, so workgroups that project outside the
+    instance mask are skipped -- the per-object volumes of the reference's real usage.  Bit-exact, and skips happen."""
+    dims, vs = (200, 120, 60), 0.004
+    origin = synth.surf_volume(200, vs, 0.7)
+    cfg = capi.make_config(dims, vs, origin)
+    scene = synth.SurfScene(dims, vs, origin)
+    rng = np.random.default_rng(8)
+    frames = []
+    for k in range(10):
+        c2w = scene.pose(k % 6, n=9)
+        depth = scene.depth(c2w, quantize=True)
+        if k == 4:
+            depth[50:60, 300:340] = np.inf          # inf x 0 = NaN outside the mask: that tile must claim nothing
+        mask = np.zeros((480, 640), np.uint8)
+        y0, x0 = int(rng.integers(100, 200)), int(rng.integers(150, 300))
+        mask[y0:y0 + 120, x0:x0 + 160] = 255
+        frames.append((c2w, depth, mask if k % 5 else None))
+    ref_t, ref_w = oracle.init_grid(dims)
+    with np.errstate(invalid="ignore"):
+        for c2w, depth, mask in frames:
+            d = depth if mask is None else oracle.mask_depth(depth, mask)
+            oracle.integrate(cfg.cam_K, c2w, d, dims, origin, vs, cfg.trunc_margin, ref_t, ref_w)
+    keep = [(cuda.from_numpy(d).cuda(), None if m is None else cuda.from_numpy(m).cuda()) for _, d, m in frames]
+    with capi.Volume(cfg) as vol:
+        vol.set_kernel_variant(8)
+        vol.shortcut_stats(True)
+        vol.integrate_frames_device([d.data_ptr() for d, _ in keep], np.stack([f[0] for f in frames]),
+                                    [None if m is None else m.data_ptr() for _, m in keep])
+        per_voxel, free, skipped = vol.shortcut_stats(False)
+        t, w = vol.download()
+    assert np.array_equal(w, ref_w) and np.array_equal(t.view(np.uint32), ref_t.view(np.uint32))
+    assert skipped > 5000 and per_voxel > 0
