@@ -213,11 +213,11 @@ def main():
     # beside it, as is the plain streaming variant in which those 16 B really move.
     H, W = depth.shape
     v = args.variant
-    fused = v in (0, 4, 5, 8)
+    fused = v in (0, 4, 5, 7, 8)
     fpl = vol.frames_per_launch if fused else 1
     full, rem = divmod(args.steps, fpl)          # K steps = `full` launches of fpl frames + one of `rem`
     launches = full + (1 if rem else 0)
-    has_summary = v in (0, 3, 4, 5, 8) or 32 <= v < 64 or 80 <= v < 96 or v >= 112
+    has_summary = v in (0, 3, 4, 5, 7, 8) or 32 <= v < 64 or 80 <= v < 96 or v >= 112
     has_elide = has_summary or v in (18, 19, 22, 23, 26, 27) or v >= 64
     flag_bytes = 4.0 * n_slab / 256.0 if has_summary else 0.0
 
@@ -283,7 +283,8 @@ def main():
         # the figure exceeds the HBM peak; "physical" prices the same launches by the bytes that really move.
         "roofline": {"bound": "hbm", "achieved": round(achieved_survey, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved_survey / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "kernel": "tsdfk::integrate_multi_inline<1,true,false,false,false,false>" if fused else
+                     "kernel": ("tsdfk::integrate_multi_inline<1,true,false,false,false,C>, C = patch classification, decided "
+                                "per launch from the previous launch's claims (DESIGN.md section 4)") if fused else
                                ("tsdfk::integrate_tile<2,true,true,false,true,false,true>" if v == 3 else f"variant {v}"),
                      "frames_per_launch": fpl, "launches": launches,
                      "kernel_ms": round(kernel_ms, 5),
@@ -343,6 +344,20 @@ def main():
                                    "value": round(n_global * n_host / dt / 1e6, 1), "unit": "Mvoxels/s",
                                    "note": "tsdf_integrate with a host depth pointer: memcpy to pinned staging + "
                                            "H2D copy + kernel per frame, Python ctypes call overhead included"}
+    if world == 1 and args.emulate_world <= 1 and args.variant == 0 and not args.no_extras:
+        # The same workload with the patch classification switched off (variant 7): every voxel of every frame is
+        # projected and tested.  On S-full the default's advantage is a property of the input (the whole volume is
+        # free space in front of a constant depth); this is the rate of the per-voxel kernel itself.
+        vol.set_kernel_variant(7)
+        vol.reset()
+        n_w, n_t = vol.frames_per_launch, 10 * vol.frames_per_launch
+        vol.integrate_sequence_timed(d_dev.data_ptr(), pose_block(0, n_w))
+        ms_p = vol.integrate_sequence_timed(d_dev.data_ptr(), pose_block(n_w, n_t)) / n_t
+        line["per_voxel_kernel"] = {"kernel_variant": 7, "ms_per_step": round(ms_p, 5), "value": round(n_global / ms_p / 1e3, 1),
+                                    "unit": "Mvoxels/s", "frames": n_t,
+                                    "note": "patch classification off: every voxel of every frame projected, sampled and tested"}
+        vol.set_kernel_variant(0)
+        vol.reset()
     if world == 1 and args.emulate_world <= 1 and args.variant == 0 and args.workload == "sfull" and not args.no_extras:
         # The same grid and kernel on the realistic workload of SURVEY.md section 8(d) (S-surf: a sphere in front of
         # a wall seen from an orbit, uint16-quantised depth): only part of the volume is updated per frame and the

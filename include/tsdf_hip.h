@@ -171,6 +171,12 @@ int32_t tsdf_frames_per_launch(const tsdf_volume *vol);
  * enables (and zeroes) or disables them.  Off by default; synchronises the stream.
  */
 int tsdf_shortcut_stats(tsdf_volume *vol, int32_t enable, uint64_t counts_out[3]);
+/*
+ * State of the per-launch decision whether to classify (default kernel variant): info_out[0] = fraction of the
+ * workgroup-frames the last counted launch claimed (-1 before the first read-back), info_out[1] = launches that have
+ * gone without classification since the last one that classified.  Synchronises the stream.
+ */
+int tsdf_classification_info(tsdf_volume *vol, double info_out[2]);
 
 /* Copy of the configuration the handle was created with. */
 int tsdf_get_config(const tsdf_volume *vol, tsdf_config *out);

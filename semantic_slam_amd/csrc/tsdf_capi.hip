@@ -91,6 +91,13 @@ struct tsdf_volume {
     // depth tile summaries of the frames of one fused launch (allocated on first use), optional counters
     float2 *d_tiles;
     unsigned int *d_shortcut_stats;
+    // adaptive use of the classification: claims of the last classifying launch, read back without blocking
+    unsigned long long *d_claims, *h_claims;
+    hipEvent_t claims_done;
+    bool claims_pending, claims_known;
+    double claims_total;        // workgroup-frames of the launch the pending read-back belongs to
+    double claim_fraction;      // claimed / total of the last launch that was read back
+    int launches_unclassified;  // since the last classifying launch
     // scratch for surface extraction (allocated on first use)
     void *d_scratch;
     size_t scratch_bytes;
@@ -198,6 +205,7 @@ tsdfk::IntegrateParams make_params(const tsdf_volume *v, const float *depth_dev,
     p.px_margin_u = (float)(1.5 + 3.2e-5 * (std::fabs((double)p.fx) + 4.0 * (c.im_width + std::fabs((double)p.cx))));
     p.px_margin_v = (float)(1.5 + 3.2e-5 * (std::fabs((double)p.fy) + 4.0 * (c.im_height + std::fabs((double)p.cy))));
     p.shortcut_stats = v->d_shortcut_stats;
+    p.claim_counter = nullptr;
     return p;
 }
 
@@ -209,8 +217,8 @@ tsdfk::IntegrateParams make_params(const tsdf_volume *v, const float *depth_dev,
 //   4        as 0 with integrate_multi<R=2> (experiment; the default fuses with R=1)
 //   5        as 0 with an XCD-aware workgroup order (experiment)
 //   6        as 0 with the frame blocks staged in device memory instead of the kernarg (A/B)
-//   8        as 0 with the per-workgroup patch classification from depth tile tables (exact; opt-in: 4x on a
-//            fully free volume, -7 % on the realistic scene, +9 % when no claim is possible)
+//   7        as 0 but never with the per-workgroup patch classification (the per-voxel kernel alone)
+//   8        as 0 but always with it (0 decides per launch from the previous launch's claims)
 //   1        scalar kernel integrate_rows<1> (any dim_x)
 //   2        first version integrate_rows<4> (one row per wavefront, no elision)
 //   16 + c   experiments: c = (rsel << 2) | (elide << 1) | nt, R = 1, 2, 4 for rsel = 0, 1, 2
@@ -404,7 +412,30 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
             for (int f = 0; f < n && masks_dev; ++f) any_mask = any_mask || masks_dev[f] != nullptr;
             dim3 grid_flat((v->chunks_per_slice + 3) / 4, 1, nz), grid_rows((mi.common.xgroups + 63) / 64, (c.dim_y + 3) / 4, nz);
             // patch classification: frames without masks, tables of at most 4 MiB per frame
-            const bool classify = v->variant == 8 && (int64_t)mi.common.tiles_w * mi.common.tiles_h <= 8192;
+            // Variant 8: always; variant 7: never; default: while it pays -- the first launch classifies, every
+            // classifying launch counts its claims, and a launch whose predecessor claimed less than a tenth of its
+            // workgroup-frames goes without (the tables and the prologue cost more than that saves), with a new probe
+            // every eighth launch.  The count is read back asynchronously: a decision never waits for the GPU.
+            if (v->claims_pending && hipEventQuery(v->claims_done) == hipSuccess) {
+                const unsigned long long w = *v->h_claims;
+                v->claim_fraction = v->claims_total > 0 ? (double)((w >> 32) + (w & 0xffffffffull)) / v->claims_total : 0.0;
+                v->claims_pending = false;
+                v->claims_known = true;
+            }
+            bool classify = (int64_t)mi.common.tiles_w * mi.common.tiles_h <= 8192 && v->variant != 7;
+            if (classify && v->variant != 8)
+                classify = !v->claims_known || v->claim_fraction >= 0.10 || v->launches_unclassified >= 7;
+            v->launches_unclassified = classify ? 0 : v->launches_unclassified + 1;
+            const bool count_claims = classify && !v->claims_pending;
+            if (count_claims) {
+                if (!v->d_claims) {
+                    HIP_TRY(hipMalloc((void **)&v->d_claims, sizeof(unsigned long long)));
+                    HIP_TRY(hipHostMalloc((void **)&v->h_claims, sizeof(unsigned long long), hipHostMallocDefault));
+                    HIP_TRY(hipEventCreateWithFlags(&v->claims_done, hipEventDisableTiming));
+                }
+                HIP_TRY(hipMemsetAsync(v->d_claims, 0, sizeof(unsigned long long), v->stream));
+                mi.common.claim_counter = v->d_claims;
+            }
             if (classify) {
                 // depth tile tables of the n frames (two small launches), then the kernel that consults them
                 auto levels = [](int n_) { int l = 0; while (n_ > 0) { ++l; n_ >>= 1; } return l; };
@@ -442,6 +473,13 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
                 hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, false, false, true>), grid_rows, block, 0, v->stream, mi);
             else
                 hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, false, false>), grid_rows, block, 0, v->stream, mi);
+            if (count_claims) {
+                const dim3 &g = v->flat ? grid_flat : grid_rows;
+                v->claims_total = (double)g.x * g.y * g.z * n;
+                HIP_TRY(hipMemcpyAsync(v->h_claims, v->d_claims, sizeof(unsigned long long), hipMemcpyDeviceToHost, v->stream));
+                HIP_TRY(hipEventRecord(v->claims_done, v->stream));
+                v->claims_pending = true;
+            }
         }
         HIP_TRY(hipGetLastError());
         return TSDF_OK;
@@ -656,6 +694,9 @@ int tsdf_destroy(tsdf_volume *v)
     if (v->d_scratch) (void)hipFree(v->d_scratch);
     if (v->d_flags) (void)hipFree(v->d_flags);
     if (v->d_tiles) (void)hipFree(v->d_tiles);
+    if (v->d_claims) (void)hipFree(v->d_claims);
+    if (v->h_claims) (void)hipHostFree(v->h_claims);
+    if (v->claims_done) (void)hipEventDestroy(v->claims_done);
     if (v->d_shortcut_stats) (void)hipFree(v->d_shortcut_stats);
     if (v->d_tsdf) (void)hipFree(v->d_tsdf);
     if (v->d_weight) (void)hipFree(v->d_weight);
@@ -884,6 +925,23 @@ int tsdf_shortcut_stats(tsdf_volume *v, int32_t enable, uint64_t counts_out[3])
     return TSDF_OK;
 }
 
+int tsdf_classification_info(tsdf_volume *v, double info_out[2])
+{
+    if (!v || !info_out) return fail(TSDF_ERR_INVALID, "tsdf_classification_info: NULL argument");
+    int rc = bind_device(v);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(v->stream));
+    if (v->claims_pending && hipEventQuery(v->claims_done) == hipSuccess) {
+        const unsigned long long w = *v->h_claims;
+        v->claim_fraction = v->claims_total > 0 ? (double)((w >> 32) + (w & 0xffffffffull)) / v->claims_total : 0.0;
+        v->claims_pending = false;
+        v->claims_known = true;
+    }
+    info_out[0] = v->claims_known ? v->claim_fraction : -1.0;
+    info_out[1] = (double)v->launches_unclassified;
+    return TSDF_OK;
+}
+
 int32_t tsdf_frames_per_launch(const tsdf_volume *v)
 {
     if (!v) return 0;
@@ -927,7 +985,7 @@ int tsdf_set_kernel_variant(tsdf_volume *v, int32_t variant)
     if (!v) return fail(TSDF_ERR_INVALID, "tsdf_set_kernel_variant: NULL handle");
     const int c = (variant - 32) & 15;
     const bool sum_ok = (variant >= 32 && variant < 112 && c < 12 && ((c >> 1) & 1)) || variant == 115 || variant == 119;
-    if (!((variant >= 0 && variant <= 6) || variant == 8) && !(variant >= 16 && variant < 28) && !sum_ok)
+    if (!(variant >= 0 && variant <= 8) && !(variant >= 16 && variant < 28) && !sum_ok)
         return fail(TSDF_ERR_INVALID, "tsdf_set_kernel_variant: unknown variant %d", variant);
     v->variant = variant;
     return TSDF_OK;

@@ -64,6 +64,9 @@ struct IntegrateParams {
     float px_margin_u, px_margin_v;
     unsigned int *shortcut_stats;
     float cz_short, cz_pad;   // per pose; copied into FramePose (see there)
+    // one word per classifying launch: (workgroup-frames claimed as free space << 32) | workgroup-frames skipped; the
+    // host reads it back asynchronously and decides whether the next launch classifies at all (null = not counted)
+    unsigned long long *claim_counter;
 };
 
 // Terms of the camera-frame point that do not depend on x (shared by a lane's voxels).

@@ -603,7 +603,12 @@ __global__ __launch_bounds__(256, R == 2 ? 6 : 1) void integrate_multi_inline(Mu
             int cls = 0;
             if (lane < mp.n_frames) cls = classify_patch(p, s_frames + lane, xa, xb, ya, yb, p.z_begin + (int)blockIdx.z);
             const unsigned long long fb = __ballot(cls == 1), sb = __ballot(cls == 2);
-            if (lane == 0) { s_bits[0] = (unsigned int)fb; s_bits[1] = (unsigned int)sb; }
+            if (lane == 0) {
+                s_bits[0] = (unsigned int)fb;
+                s_bits[1] = (unsigned int)sb;
+                if (p.claim_counter != nullptr && (fb | sb) != 0ull)
+                    atomicAdd(p.claim_counter, ((unsigned long long)__popcll(fb) << 32) | (unsigned long long)__popcll(sb));
+            }
         }
         __syncthreads();
         free_frames = s_bits[0];

@@ -119,3 +119,41 @@ def test_patch_classification_with_instance_masks(cuda, oracle):
         t, w = vol.download()
     assert np.array_equal(w, ref_w) and np.array_equal(t.view(np.uint32), ref_t.view(np.uint32))
     assert skipped > 5000 and per_voxel > 0
+
+
+def test_classification_is_dropped_when_it_claims_nothing_and_probed_again(cuda, oracle):
+    """Default variant: the first launch classifies and counts; with one invalid pixel in every depth tile and the
+    volume in view nothing can be claimed, so the following launches go without, except a probe every eighth.  Then a
+    clean frame stream: the probe finds everything claimable and classification stays on.  Bit-exact throughout."""
+    dims, vs = (256, 32, 16), 0.002
+    origin = synth.surf_volume(256, vs, 0.7)
+    cfg = capi.make_config(dims, vs, origin)
+    far = origin[2] + dims[2] * vs
+    holes = np.full((480, 640), far + 0.5, np.float32)
+    holes[::16, ::16] = 0.0
+    clean = np.full((480, 640), far + 0.5, np.float32)
+    pose = synth.identity_pose()
+    ref_t, ref_w = oracle.init_grid(dims)
+    d_holes, d_clean = cuda.from_numpy(holes).cuda(), cuda.from_numpy(clean).cuda()
+    with capi.Volume(cfg) as vol:
+        fpl = vol.frames_per_launch
+        seen = []
+        for launch in range(12):
+            vol.integrate_frames_device([d_holes.data_ptr()] * fpl, np.stack([pose] * fpl))
+            for _ in range(fpl):
+                oracle.integrate(cfg.cam_K, pose, holes, dims, origin, vs, cfg.trunc_margin, ref_t, ref_w)
+            seen.append(vol.classification_info())
+        assert seen[0][0] == 0.0 and seen[0][1] == 0            # the first launch classified, claimed nothing
+        assert max(s[1] for s in seen) == 7 and seen[-1][1] < 7  # ... then 7 launches without, a probe, and again
+        for launch in range(3):
+            vol.integrate_frames_device([d_clean.data_ptr()] * fpl, np.stack([pose] * fpl))
+            for _ in range(fpl):
+                oracle.integrate(cfg.cam_K, pose, clean, dims, origin, vs, cfg.trunc_margin, ref_t, ref_w)
+        for launch in range(9):   # reach the next probe
+            vol.integrate_frames_device([d_clean.data_ptr()] * fpl, np.stack([pose] * fpl))
+            for _ in range(fpl):
+                oracle.integrate(cfg.cam_K, pose, clean, dims, origin, vs, cfg.trunc_margin, ref_t, ref_w)
+        frac, idle = vol.classification_info()
+        assert frac > 0.9 and idle == 0
+        t, w = vol.download()
+    assert np.array_equal(w, ref_w) and np.array_equal(t.view(np.uint32), ref_t.view(np.uint32))

@@ -32,7 +32,7 @@ def counter_avg(d, counter, kernel_substr):
 def main():
     tag, stats_dir, fetch_dir, write_dir, key = sys.argv[1:6]
     # the default Integrate kernel; bench.py also launches the streaming variant (different template args)
-    kernel = sys.argv[6] if len(sys.argv) > 6 else "integrate_multi_inline<1, true, false, false, false, false>"
+    kernel = sys.argv[6] if len(sys.argv) > 6 else "integrate_multi_inline<1, true, false, false, false, "   # both instantiations (classification on / off)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = os.path.join(root, "profiles")
     os.makedirs(out, exist_ok=True)
