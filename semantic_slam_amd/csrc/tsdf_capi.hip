@@ -416,11 +416,15 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
             // classifying launch counts its claims, and a launch whose predecessor claimed less than a tenth of its
             // workgroup-frames goes without (the tables and the prologue cost more than that saves), with a new probe
             // every eighth launch.  The count is read back asynchronously: a decision never waits for the GPU.
-            if (v->claims_pending && hipEventQuery(v->claims_done) == hipSuccess) {
-                const unsigned long long w = *v->h_claims;
-                v->claim_fraction = v->claims_total > 0 ? (double)((w >> 32) + (w & 0xffffffffull)) / v->claims_total : 0.0;
-                v->claims_pending = false;
-                v->claims_known = true;
+            if (v->claims_pending) {
+                if (hipEventQuery(v->claims_done) == hipSuccess) {
+                    const unsigned long long w = *v->h_claims;
+                    v->claim_fraction = v->claims_total > 0 ? (double)((w >> 32) + (w & 0xffffffffull)) / v->claims_total : 0.0;
+                    v->claims_pending = false;
+                    v->claims_known = true;
+                } else {
+                    (void)hipGetLastError();   // "not ready" is an answer, not an error to be found by a later check
+                }
             }
             bool classify = (int64_t)mi.common.tiles_w * mi.common.tiles_h <= 8192 && v->variant != 7;
             if (classify && v->variant != 8)
