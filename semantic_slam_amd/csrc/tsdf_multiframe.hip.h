@@ -367,6 +367,10 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
             if (skip) continue;
             if (all_free) {
                 // every voxel of the wavefront: valid pixel, diff >= trunc (dist = 1), none in the band
+                if (touched[0] && ones[0] && (fl[0] & 2u)) {   // steady state of a free-space row: only the weights move
+                    w4[0].x += 1.0f; w4[0].y += 1.0f; w4[0].z += 1.0f; w4[0].w += 1.0f;
+                    continue;
+                }
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     rowany[r] = true;
