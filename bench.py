@@ -292,10 +292,12 @@ def main():
                      "algorithmic_bytes_per_unit": 16,
                      "units_per_launch": int(n_upd_per_frame * (fpl if full else rem)),
                      "unit_name": "voxel updated by one frame (SURVEY.md section 8d: 4 B TSDF + 4 B weight, read and written)",
-                     "frac_above_one": "the launch applies frames_per_launch frames to voxels held in registers and the "
-                                       "free-space summary elides TSDF traffic whose result is provably unchanged, so the "
-                                       "16 B per update of the model do not move (traffic = PMC bytes per launch); the kernel "
-                                       "is bound by instruction issue (DESIGN.md section 4), not by HBM",
+                     "frac_above_one": "the launch applies frames_per_launch frames to voxels held in registers, the free-space "
+                                       "summary elides TSDF traffic whose result is provably unchanged, and workgroups whose "
+                                       "whole patch a depth tile table proves free space (this input: all of them) or "
+                                       "untouched are updated without projecting a voxel -- bit-identical results, so the "
+                                       "16 B per update of the model do not move (traffic = PMC bytes per launch); "
+                                       "per_voxel_kernel is the same input with that classification off",
                      "physical": {"bytes_per_launch": int(bytes_per_launch), "achieved": round(achieved, 1),
                                   "frac": round(achieved / HBM_PEAK_GBS, 4), "unit": "GB/s",
                                   "voxels_touched_per_launch": int(n_touched),
