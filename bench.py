@@ -1,21 +1,38 @@
 #!/usr/bin/env python3
-"""bench.py -- Mvoxels/s of the HIP TSDF Integrate path (BASELINE.json metric).
+"""bench.py -- Mvoxels/s of the HIP TSDF Integrate path (BASELINE.json metric) with its HBM roofline.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--grid 512] [--workload sfull|ssurf]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--grid 512] [--workload sband|sfull|ssurf|traj]
+                    [--mode frame|fused]
 
-One "step" = one Integrate of one 640x480 depth frame into the whole grid.  At N = 1 the
-workload is BASELINE.json configs[1]: 512^3 @ 5 mm, synthetic depth + pose stream (S-full,
-SURVEY.md section 8d: every voxel updated every frame).  For N > 1 every rank owns one z-slab and
-there is no data-path collective (voxels are independent); by default the scaling is WEAK: each rank's
-slab holds as many voxels as the whole N = 1 grid and the global grid grows inside the same physical
-box (1024^3 @ 2.5 mm at N = 8); --scaling strong cuts the 512^3 grid itself.  Launch with
-torch.distributed.run as the driver does.  The depth frame is resident in HBM before the timed
-region.  Rank 0 prints one JSON line.
+One "step" = one Integrate of one 640x480 depth frame into the whole grid.  At N = 1 the workload is
+BASELINE.json configs[1] -- 512^3 @ 5 mm, synthetic depth + pose stream -- as S-band (semantic_slam_amd/synth.py):
+the volume wholly inside the frustum, every voxel updated by every frame AND inside the truncation band, so both
+divisions run, every TSDF value changes every frame and all 16 B per voxel (TSDF + weight, read + write) have to
+move: nothing about the update can be elided.  Mode "frame" (the headline) issues one kernel launch per step --
+the reference's call shape, TSDF::Integrate once per frame (ref: src/tsdf.cu:135-168) -- so the SURVEY section 8(d)
+byte model (16 B per updated voxel + one pass over the depth frame) is exactly what a launch must move and
+roofline.frac is a true HBM fraction.  Mode "fused" hands the frames to tsdf_integrate_frames_device, which applies
+up to 32 of them per pass over the volume with the voxels held in registers (bit-identical results, more voxel
+updates per second, bound by instruction issue instead of HBM); it is reported beside the headline.
+
+Timing: the depth frame(s) are resident in HBM before the timed region.  After the warm-up (at least --warmup steps
+and two full launches) the K-step sequence is repeated until at least 0.3 s of device time has been timed, between
+a barrier + torch.cuda.synchronize() on both sides; ms_per_step = wall / (K x repeats), max over ranks; HIP events
+on the handle's stream give the kernel time.  For N > 1 every rank owns one z-slab (no data-path collective; by
+default WEAK scaling: each rank's slab holds as many voxels as the whole N = 1 grid); after the timed region the
+ranks run the one-voxel halo exchange (RCCL) and the halo-fed extraction once and report its time.  Launch with
+torch.distributed.run as the driver does.  Rank 0 prints one JSON line.
 """
 import argparse
+import csv
+import glob
 import json
+import math
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -23,17 +40,21 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md, HBM)
+MIN_TIMED_MS = 300.0       # the K-step sequence is repeated until this much device time has been timed
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=640)
-    ap.add_argument("--warmup", type=int, default=64)
-    ap.add_argument("--grid", type=int, default=512, help="grid edge in voxels (512 or 1024)")
-    ap.add_argument("--workload", default="sfull", choices=["sfull", "ssurf"])
-    ap.add_argument("--variant", type=int, default=0, help="kernel variant (see DESIGN.md)")
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--grid", type=int, default=0, help="grid edge in voxels (default 512; 1024 for --workload traj)")
+    ap.add_argument("--workload", default="sband", choices=["sband", "sfull", "ssurf", "traj"])
+    ap.add_argument("--mode", default="", choices=["", "frame", "fused"],
+                    help="frame: one launch per step (default for sband / sfull); fused: up to 32 frames per pass over "
+                         "the volume through tsdf_integrate_frames_device (default for ssurf / traj)")
+    ap.add_argument("--variant", type=int, default=-1, help="force a kernel variant (DESIGN.md; overrides --mode)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = every rank integrates a slab as large as the whole N = 1 grid (the global grid "
                          "grows with N: 512^3 -> 512x512x1024 -> 512x1024x1024 -> 1024^3 at N = 1, 2, 4, 8, same physical "
@@ -42,61 +63,187 @@ def parse():
                     help="single-GPU rehearsal of one rank of an N-GPU job: integrate only rank 0's z-slab of N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
-                    help="only the contract's timed region (for profiler runs: no streaming-variant, host-depth or "
-                         "S-surf companion legs, which launch more kernels after it)")
+                    help="only the contract's timed region (for profiler runs: no companion legs, which launch more kernels)")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="do not measure roofline.traffic (two short rocprofv3 --pmc child runs of this script)")
+    ap.add_argument("--no-extract", action="store_true", help="N > 1: skip the halo exchange + extraction after the timed region")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if not a.grid:
+        a.grid = 1024 if a.workload == "traj" else 512
+    if not a.mode:
+        a.mode = "frame" if a.workload in ("sband", "sfull") else "fused"
+    return a
 
 
-def cpu_baseline(args, dims, vs, origin, cfg, depth, poses, n_upd_expected_per_slice):
-    """Time the CPU oracle (and the reference's own kernel body when oracle/_ref was built) on a
-    bounded z-slab sample of the same workload, all host threads.  Checker code: it is
-    measured here as the baseline, never used to produce the GPU result."""
+# ------------------------------------------------------------------------------------------------------------
+# workloads
+# ------------------------------------------------------------------------------------------------------------
+class Workload:
+    """origin, truncation margin, base pose, the cam2world stream and the depth frame(s) it comes with."""
+
+    def __init__(self, name, dims, vs):
+        from semantic_slam_amd import synth
+        self.name, self.dims, self.vs = name, dims, vs
+        self.trunc = None            # None = the reference's 5 x voxel
+        self.base2world = None
+        self.full_coverage = False
+        if name in ("sband", "sfull"):
+            self.origin = synth.sband_volume(dims, vs) if name == "sband" else synth.sfull_volume(dims, vs)
+            pose = synth.sband_pose if name == "sband" else synth.sfull_pose
+            self.trunc = synth.SBAND_TRUNC if name == "sband" else None
+            self.poses = np.stack([pose(k) for k in range(64)])
+            self.depths = [synth.sfull_depth()]                      # one constant frame, shared by every pose
+            self.full_coverage = True
+            self.desc = ("every voxel updated every frame inside the truncation band (dist < 1, both divisions, every TSDF "
+                         "value changes): all 16 B per voxel move" if name == "sband" else
+                         "every voxel updated every frame with dist = 1 (free space)")
+        elif name == "ssurf":
+            self.origin = synth.surf_volume(max(dims), vs, 1.0)
+            scene = synth.SurfScene(dims, vs, self.origin)
+            self.poses = np.stack([scene.pose(k, 64) for k in range(64)])
+            self.depths = [scene.depth(p, quantize=True) for p in self.poses]   # re-rendered per pose
+            self.desc = "sphere + wall seen from a 64-pose orbit, depth re-rendered per pose and quantised at 1/5000 m"
+        else:   # traj: BASELINE configs[2]
+            from semantic_slam_amd import ingest
+            gold = os.path.join(ROOT, "tests", "golden", "fr3_office_keyframes.npz")
+            Twc = ingest.pose_inverse(np.load(gold, allow_pickle=False)["Tcw"])
+            self.base2world = Twc[0].ravel().copy()
+            half = max(dims[0], dims[1]) * vs / 2.0
+            self.origin = np.array([-half, -half, 0.6], np.float32)
+            scene = synth.SurfScene(dims, vs, self.origin)
+            from semantic_slam_amd import capi
+            ok, binv = capi.invert_matrix(self.base2world)
+            self.poses = np.stack([T.ravel() for T in Twc])
+            # what the camera sees from each keyframe: rendered from the relative pose the library will compose
+            self.depths = [scene.depth(capi.multiply_matrix(binv, p), quantize=True) for p in self.poses]
+            self.desc = (f"the {len(self.poses)} keyframe poses of the reference's saved fr3_office run (result/rgbd/bundle.txt), "
+                         "base = first keyframe, sphere + wall depth re-rendered per pose, quantised at 1/5000 m")
+        self.n_pose = len(self.poses)
+
+    def block(self, start, n):
+        idx = [(start + i) % self.n_pose for i in range(n)]
+        return self.poses[idx], idx
+
+
+def grid_for(args, world):
+    """Global dims and voxel size; weak scaling grows the grid with N inside the same physical box."""
+    D = args.grid
+    vs = {512: 0.005, 1024: 0.002}.get(D, 2.56 / D)
+    dims = [D, D, D]
+    part_world = args.emulate_world if (args.emulate_world > 1 and world == 1) else world
+    if args.scaling == "weak" and part_world > 1:
+        # per-rank work fixed: z, then y, then x doubled in turn, voxels halved whenever z is doubled; a rank count that
+        # is not a power of two just gets N x the slices
+        k, n = 0, part_world
+        while n % 2 == 0:
+            n //= 2
+            k += 1
+        if n == 1:
+            for i in range(k):
+                dims[2 - i % 3] *= 2
+            vs = vs / 2 ** ((k + 2) // 3)
+        else:
+            dims[2] *= part_world
+            vs = vs / part_world
+    return tuple(dims), vs, part_world
+
+
+# ------------------------------------------------------------------------------------------------------------
+# CPU baseline (checker code timed as the baseline; never used to produce the GPU result)
+# ------------------------------------------------------------------------------------------------------------
+def cpu_baseline(args, W, cam_K, trunc):
     from oracle.oracle import Oracle, Ref
     orc = Oracle()
-    D = dims[0]
-    nz = min(D, 64)                      # sample: the middle nz slices of the grid
-    zb = (D - nz) // 2
+    dims, vs, origin = W.dims, W.vs, W.origin
+    Dz = dims[2]
+    nz = min(Dz, 64)                      # sample: the middle nz slices of the grid
+    zb = (Dz - nz) // 2
     threads = orc.max_threads()
+    base = W.base2world if W.base2world is not None else np.eye(4, dtype=np.float32).ravel()
+    c2b = [orc.cam2base(base, p) for p in W.poses]
+    depth = lambda i: W.depths[i % len(W.depths)]
     t, w = orc.init_grid(dims, zb, zb + nz)
-    orc.integrate(cfg.cam_K, poses[0], depth, dims, origin, vs, cfg.trunc_margin, t, w, z_begin=zb,
-                  z_end=zb + nz, threads=threads)  # warm-up: page in the slab
+    orc.integrate(cam_K, c2b[0], depth(0), dims, origin, vs, trunc, t, w, z_begin=zb, z_end=zb + nz, threads=threads)  # page in
     frames, t0, n_upd = 0, time.perf_counter(), 0
     while True:
-        n_upd += orc.integrate(cfg.cam_K, poses[(frames + 1) % len(poses)], depth, dims, origin, vs,
-                               cfg.trunc_margin, t, w, z_begin=zb, z_end=zb + nz, threads=threads)
+        i = (frames + 1) % W.n_pose
+        n_upd += orc.integrate(cam_K, c2b[i], depth(i), dims, origin, vs, trunc, t, w, z_begin=zb, z_end=zb + nz, threads=threads)
         frames += 1
         el = time.perf_counter() - t0
         if el > args.cpu_seconds or frames >= 200:
             break
-    out = {"value": round(nz * D * D * frames / el / 1e6, 1), "unit": "Mvoxels/s", "cores": threads,
-           "kind": "port",
-           "sample": f"oracle/tsdf_oracle.c (OpenMP over rows), {frames} frames of the same workload into "
-                     f"z-slab [{zb},{zb + nz}) of the {D}^3 grid, {el:.1f} s"}
-    if n_upd_expected_per_slice is not None:
-        assert n_upd == frames * nz * n_upd_expected_per_slice, "S-full must update every voxel (N_upd == N)"
+    per_slice = dims[0] * dims[1]
+    out = {"value": round(nz * per_slice * frames / el / 1e6, 1), "unit": "Mvoxels/s", "cores": threads, "kind": "port",
+           "sample": f"oracle/tsdf_oracle.c (OpenMP over rows), {frames} frames of the same workload into z-slab "
+                     f"[{zb},{zb + nz}) of the {dims[0]}x{dims[1]}x{dims[2]} grid, {el:.1f} s"}
+    if W.full_coverage:
+        assert n_upd == frames * nz * per_slice, "full-coverage workload must update every voxel (N_upd == N)"
     ref = None
-    if Ref.available() and D <= 1024:
-        # the reference body has no slab form: give it a grid that IS the slab (origin shifted in z
-        # on the host; timing only, values are not compared here)
+    if Ref.available() and max(dims) <= 1024:
+        # the reference body has no slab form: give it a grid that IS the slab (origin shifted in z on the host;
+        # timing only, values are not compared here)
         r = Ref()
-        rd = (D, D, nz)
+        rd = (dims[0], dims[1], nz)
         ro = np.array([origin[0], origin[1], origin[2] + zb * vs], np.float32)
         t2, w2 = orc.init_grid(rd)
-        r.integrate(cfg.cam_K, poses[0], depth, rd, ro, vs, cfg.trunc_margin, t2, w2, threads=threads)
+        r.integrate(cam_K, c2b[0], depth(0), rd, ro, vs, trunc, t2, w2, threads=threads)
         f2, t0 = 0, time.perf_counter()
         while True:
-            r.integrate(cfg.cam_K, poses[(f2 + 1) % len(poses)], depth, rd, ro, vs, cfg.trunc_margin, t2, w2,
-                        threads=threads)
+            i = (f2 + 1) % W.n_pose
+            r.integrate(cam_K, c2b[i], depth(i), rd, ro, vs, trunc, t2, w2, threads=threads)
             f2 += 1
             el2 = time.perf_counter() - t0
             if el2 > args.cpu_seconds / 2 or f2 >= 200:
                 break
-        ref = {"value": round(nz * D * D * f2 / el2 / 1e6, 1), "unit": "Mvoxels/s", "cores": threads,
-               "kind": "reference",
-               "sample": f"GpuIntegrate body of the reference (src/tsdf.cu:15-60) built for the host by "
-                         f"oracle/Makefile, {f2} frames into a {D}x{D}x{nz} grid, {el2:.1f} s"}
+        ref = {"value": round(nz * per_slice * f2 / el2 / 1e6, 1), "unit": "Mvoxels/s", "cores": threads, "kind": "reference",
+               "sample": f"GpuIntegrate of the reference (src/tsdf.cu:15-60) built for the host by oracle/Makefile, "
+                         f"{f2} frames into a {rd[0]}x{rd[1]}x{rd[2]} grid, {el2:.1f} s"}
     return out, ref
+
+
+# ------------------------------------------------------------------------------------------------------------
+# roofline.traffic, measured by this run: two short rocprofv3 --pmc passes over a child run of this script
+# ------------------------------------------------------------------------------------------------------------
+def measure_traffic(args, kernel_substr, child_steps):
+    """HBM bytes per launch of the dominant kernel from the PMC counters, collected as MI355X_MICROARCH.md prescribes:
+    FETCH_SIZE and WRITE_SIZE in separate passes (they do not fit one), KiB units, FETCH_SIZE doubled on gfx950 for
+    wide coalesced reads, WRITE_SIZE exact.  Returns (bytes or None, note)."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    vals = {}
+    tmp = os.environ.get("TMPDIR") or "/tmp"
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="bench_pmc_", dir=tmp)
+        cmd = [exe, "--pmc", counter, "-d", d, "-o", "p", "--output-format", "csv", "--",
+               sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--workload", args.workload,
+               "--grid", str(args.grid), "--mode", args.mode, "--variant", str(args.variant),
+               "--steps", str(child_steps), "--warmup", "2"]
+        try:
+            env = dict(os.environ, TMPDIR=tmp)
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+                env.pop(k, None)
+            p = subprocess.run(cmd, cwd=tmp, env=env, timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if p.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {p.returncode}): {p.stderr.decode(errors='replace')[-200:]}"
+            v = [float(r["Counter_Value"]) for r in csv.DictReader(open(files[0]))
+                 if r["Counter_Name"] == counter and kernel_substr in r["Kernel_Name"]]
+            if not v:
+                return None, f"no dispatch of {kernel_substr} in the {counter} pass"
+            vals[counter] = (float(np.median(v)), len(v))
+        except Exception as e:   # noqa: BLE001 -- the traffic figure is optional, the bench line is not
+            return None, f"rocprofv3 --pmc {counter}: {e!r}"[:300]
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    fetch, write = 2.0 * vals["FETCH_SIZE"][0] * 1024.0, vals["WRITE_SIZE"][0] * 1024.0
+    note = (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes over a short child run of "
+            f"the same workload), median over {vals['FETCH_SIZE'][1]} / {vals['WRITE_SIZE'][1]} dispatches of the kernel; KiB units, "
+            f"FETCH_SIZE x 2 (gfx950 counts wide coalesced reads at half their bytes), WRITE_SIZE exact: "
+            f"read {fetch / 1e6:.1f} MB + written {write / 1e6:.1f} MB per launch")
+    return fetch + write, note
 
 
 def main():
@@ -113,7 +260,7 @@ def main():
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     # TSDF_BENCH_BACKEND=gloo: rehearsal of the N-rank path on a box with fewer GPUs than ranks (ranks share
-    # devices, the two scalars of the timing reduction travel through gloo); the driver's runs use RCCL.
+    # devices, buffers travel through gloo on the host); the driver's runs use RCCL.
     backend = os.environ.get("TSDF_BENCH_BACKEND", "nccl")
     if backend == "gloo":
         local_rank = local_rank % torch.cuda.device_count()
@@ -126,37 +273,11 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    comm_dev = "cpu" if backend == "gloo" else "cuda"
 
+    dims, vs, part_world = grid_for(args, world)
+    W = Workload(args.workload, dims, vs)
     D = args.grid
-    vs = {512: 0.005, 1024: 0.002}.get(D, 2.56 / D)
-    dims = [D, D, D]
-    part_world = args.emulate_world if (args.emulate_world > 1 and world == 1) else world
-    if args.scaling == "weak" and part_world > 1:
-        # per-rank work fixed: grow the grid with N inside the same physical box (z, then y, then x doubled in
-        # turn, voxels halved whenever z is doubled); a rank count that is not a power of two just gets N x the slices
-        k, n = 0, part_world
-        while n % 2 == 0:
-            n //= 2
-            k += 1
-        if n == 1:
-            for i in range(k):
-                dims[2 - i % 3] *= 2
-            vs = vs / 2 ** ((k + 2) // 3)
-        else:
-            dims[2] *= part_world
-            vs = vs / part_world
-    dims = tuple(dims)
-    if args.workload == "sfull":
-        origin = synth.sfull_volume(dims, vs)
-        depth = synth.sfull_depth()
-        n_pose = 64
-        poses = np.stack([synth.sfull_pose(k) for k in range(n_pose)])
-    else:
-        origin = synth.surf_volume(max(dims), vs, 1.0)
-        scene = synth.SurfScene(dims, vs, origin)
-        n_pose = 64
-        poses = np.stack([scene.pose(k, n_pose) for k in range(n_pose)])
-        depth = scene.depth(poses[0], quantize=True)  # one resident frame, orbiting camera
 
     # z-slab of this rank (ref layout is z-major, so a slab is one contiguous range)
     Dz = dims[2]
@@ -164,13 +285,20 @@ def main():
     if args.emulate_world > 1 and world == 1:
         zb, ze = 0, Dz // args.emulate_world
     n_global = dims[0] * dims[1] * dims[2]
-    cfg = capi.make_config(dims, vs, origin, z_begin=zb, z_end=ze, device=local_rank)
+    cfg = capi.make_config(dims, vs, W.origin, trunc=W.trunc, base2world=W.base2world, z_begin=zb, z_end=ze, device=local_rank)
     vol = capi.Volume(cfg)
-    vol.set_kernel_variant(args.variant)
-    d_dev = torch.from_numpy(depth).cuda()
+    variant = args.variant if args.variant >= 0 else (3 if args.mode == "frame" else 0)
+    vol.set_kernel_variant(variant)
+    fpl = vol.frames_per_launch
+    d_dev = [torch.from_numpy(d).cuda() for d in W.depths]
+    H, Wd = W.depths[0].shape
 
-    def pose_block(start, n):
-        return np.stack([poses[(start + i) % n_pose] for i in range(n)])
+    def run_block(v, start, n):
+        """n consecutive steps queued back to back on the handle's stream; device milliseconds (HIP events there)."""
+        poses, idx = W.block(start, n)
+        if len(d_dev) == 1:
+            return v.integrate_sequence_timed(d_dev[0].data_ptr(), poses)
+        return v.integrate_frames_timed([d_dev[i].data_ptr() for i in idx], poses)
 
     def fence():
         torch.cuda.synchronize()
@@ -178,211 +306,252 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.warmup > 0:
-        vol.integrate_sequence_timed(d_dev.data_ptr(), pose_block(0, args.warmup))
+    if args.pmc_child:   # profiled child of measure_traffic: the launches only
+        run_block(vol, 0, args.warmup)
+        run_block(vol, args.warmup, args.steps)
+        vol.close()
+        return
+
+    # ---- warm-up: at least W steps, at least two full launches, at least 8 steps -------------------------------
+    K = args.steps
+    n_warm = max(args.warmup, 2 * fpl, 8)
+    run_block(vol, 0, n_warm)
+    cal_ms = run_block(vol, n_warm, K)                 # calibration block (also warm): how long K steps take
+    frames_done = n_warm + K
+    repeats = max(1, int(math.ceil(1.2 * MIN_TIMED_MS / max(cal_ms, 1e-3))))   # 20 % margin: the calibration block may run slow
+    if dist is not None:   # every rank times the same number of blocks
+        rt = torch.tensor([repeats], dtype=torch.int64, device="cpu" if backend == "gloo" else "cuda")
+        dist.all_reduce(rt, op=dist.ReduceOp.MAX)
+        repeats = int(rt[0])
+
+    # ---- timed region: the K-step sequence, `repeats` times ------------------------------------------------------
     fence()
     t0 = time.perf_counter()
-    # exactly K steps, queued back to back on the handle's stream, HIP events around them
-    kernel_ms_total = vol.integrate_sequence_timed(d_dev.data_ptr(), pose_block(args.warmup, args.steps))
+    kernel_ms_total = 0.0
+    for r in range(repeats):
+        kernel_ms_total += run_block(vol, frames_done + r * K, K)
     fence()
     wall = time.perf_counter() - t0
+    timed_steps = K * repeats
+    frames_done += timed_steps
 
     tt = torch.tensor([wall, kernel_ms_total], dtype=torch.float64, device="cpu" if backend == "gloo" else "cuda")
     if dist is not None:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     wall, kernel_ms_total = float(tt[0]), float(tt[1])
 
-    # --- what was integrated: count updates on this rank's slab ------------------------------
+    # ---- what was integrated: count updates on this rank's slab ------------------------------------------------
     t_host, w_host = vol.download()
-    n_frames = args.warmup + args.steps
     n_slab = vol.n_voxels
     upd_total = float(w_host.astype(np.float64).sum())  # each update adds exactly 1 to one weight
-    if args.workload == "sfull":
-        assert w_host.min() == w_host.max() == float(n_frames), "S-full: every voxel every frame"
-        assert np.all(t_host == 1.0)
-    n_upd_per_frame = upd_total / n_frames
+    if W.full_coverage:
+        assert w_host.min() == w_host.max() == float(frames_done), "full coverage: every voxel every frame"
+        if args.workload == "sfull":
+            assert np.all(t_host == 1.0)
+        else:
+            assert 0.0 < t_host.min() and t_host.max() < 1.0, "S-band: every TSDF value inside the truncation band"
+    n_upd_per_frame = upd_total / frames_done
     del t_host, w_host
 
-    # --- roofline of the dominant kernel on this rank ---------------------------------------------
-    # The default path applies FPL (tsdf_frames_per_launch: 32) consecutive frames per pass over the volume:
-    # one launch = FPL steps.  Bytes one launch must move (DESIGN.md "Bytes model"): 4 B weight read +
-    # 4 B weight write per voxel touched by any of its frames; the TSDF value is read only where the
-    # free-space summary does not already say "this 256-voxel segment is all ones" and written only
-    # where it changes; the summary words; FPL passes over the depth frame; the parameters.
-    # SURVEY.md section 8(d) priced every updated voxel of every frame at 16 B; that figure is reported
-    # beside it, as is the plain streaming variant in which those 16 B really move.
-    H, W = depth.shape
-    v = args.variant
-    fused = v in (0, 4, 5, 7, 8)
-    fpl = vol.frames_per_launch if fused else 1
-    full, rem = divmod(args.steps, fpl)          # K steps = `full` launches of fpl frames + one of `rem`
-    launches = full + (1 if rem else 0)
-    has_summary = v in (0, 3, 4, 5, 7, 8) or 32 <= v < 64 or 80 <= v < 96 or v >= 112
-    has_elide = has_summary or v in (18, 19, 22, 23, 26, 27) or v >= 64
-    flag_bytes = 4.0 * n_slab / 256.0 if has_summary else 0.0
-
-    def launch_bytes(n):
-        """(algorithmic bytes, SURVEY's 16-B figure, voxels touched, TSDF values read, written) of one launch of n frames."""
-        touched = min(float(n_slab), n * n_upd_per_frame)   # exact for sfull; upper bound otherwise
-        if args.workload == "sfull":
-            # every voxel updated every frame, every TSDF value stays exactly 1 (asserted above)
-            t_read = 0.0 if has_summary else touched
-            t_written = 0.0 if has_elide else touched
-        else:
-            t_read = t_written = touched
-        b = 8.0 * touched + 4.0 * t_read + 4.0 * t_written + flag_bytes + n * (4.0 * H * W + 100.0)
-        return b, n * (16.0 * n_upd_per_frame + 4.0 * H * W + 100.0), touched, t_read, t_written
-
-    count_note = "exact" if args.workload == "sfull" else \
-        "upper bound (TSDF reads/writes elided on the device are not counted there)"
-    bytes_per_launch, bytes_survey, n_touched, n_t_read, n_t_written = launch_bytes(fpl if full else rem)
-    total_bytes = full * launch_bytes(fpl)[0] + (launch_bytes(rem)[0] if rem else 0.0)
-    total_survey = full * launch_bytes(fpl)[1] + (launch_bytes(rem)[1] if rem else 0.0)
-    kernel_ms = kernel_ms_total / launches
-    achieved = total_bytes / (kernel_ms_total * 1e-3) / 1e9
-    achieved_survey = total_survey / (kernel_ms_total * 1e-3) / 1e9
+    # ---- after the timed region, N > 1: the one-voxel halo (RCCL) and the extraction it feeds --------------------
+    extraction = None
+    if world > 1 and not args.no_extract:
+        from semantic_slam_amd.sharded import ShardedVolume
+        sv = ShardedVolume(dims, lambda a, b: vol, dist=dist, comm_device=comm_dev)
+        assert (sv.z_begin, sv.z_end) == (zb, ze)
+        fence()
+        t1 = time.perf_counter()
+        halo = sv.halo_exchange()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        n_x = len(vol.extract_crossings(halo))
+        t3 = time.perf_counter()
+        et = torch.tensor([t2 - t1, t3 - t2, float(n_x)], dtype=torch.float64, device="cpu" if backend == "gloo" else "cuda")
+        dist.all_reduce(et[:2], op=dist.ReduceOp.MAX)
+        dist.all_reduce(et[2:], op=dist.ReduceOp.SUM)
+        extraction = {"halo_exchange_ms": round(float(et[0]) * 1e3, 3), "crossings_ms": round(float(et[1]) * 1e3, 3),
+                      "vertices": int(et[2]), "halo_bytes_per_boundary": 8 * dims[0] * dims[1],
+                      "backend": "rccl (buffers in HBM, device-to-device slice copy, device-resident halo)" if comm_dev == "cuda"
+                                 else "gloo (host buffers)",
+                      "note": "after the timed region: every rank sends its first slice to the rank below (grouped isend/irecv), "
+                              "then extracts its slab's zero crossings with the received slice as +z neighbour; max over ranks"}
 
     if rank != 0:
+        vol.close()
         if dist is not None:
             dist.destroy_process_group()
         return
 
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.isfile(tpath):
-        try:
-            rec = json.load(open(tpath))
-            key = f"{args.workload}_{D}_slab{ze - zb}" + ("" if args.variant == 0 else f"_v{args.variant}")
-            if dims != (D, D, D):
-                key += "_" + "x".join(str(d) for d in dims)
-            if key in rec:
-                traffic = rec[key]["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
+    # ---- roofline of the dominant kernel on this rank -------------------------------------------------------------
+    frame_bytes = 4.0 * H * Wd + 100.0
+    if fpl == 1:
+        # one launch per step: SURVEY.md section 8(d) to the letter -- 16 B per voxel updated (TSDF + weight, read and
+        # written) + one pass over the depth frame + the parameters
+        launches = timed_steps
+        units_per_launch = n_upd_per_frame
+        alg_bytes = 16.0 * units_per_launch + frame_bytes
+        unit_name = "voxel updated by the launch's frame (SURVEY.md section 8d: 4 B TSDF + 4 B weight, read and written)"
+        bytes_model = "16 B x voxels updated + 4*H*W (one pass over the depth frame) + 100 (intrinsics, pose)"
+    else:
+        # up to fpl frames per pass with the voxels held in registers: a launch has to read and write each voxel it
+        # touches once, whatever the number of its frames that update it, and to read each of its depth frames once
+        full, rem = divmod(K, fpl)
+        launches = (full + (1 if rem else 0)) * repeats
+        frames_per = K / (full + (1 if rem else 0))
+        units_per_launch = min(float(n_slab), frames_per * n_upd_per_frame)
+        alg_bytes = 16.0 * units_per_launch + frames_per * frame_bytes
+        unit_name = ("voxel touched by the launch (4 B TSDF + 4 B weight, read once and written once per launch; exact for "
+                     "full-coverage workloads, an upper bound otherwise)")
+        bytes_model = "16 B x voxels touched by the launch + frames per launch x (4*H*W + 100)"
+    kernel_ms = kernel_ms_total / launches
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    if fpl == 1:
+        kname = ("tsdfk::integrate_tile<2, true, true, false, true, false, true, false>" if cfg.dim_x % 256 == 0 else
+                 "tsdfk::integrate_multi_single<true, true>") if variant in (0, 3) else f"variant {variant}"
+        ksub = "integrate_tile<" if cfg.dim_x % 256 == 0 else "integrate_multi_single<"
+    else:
+        kname = "tsdfk::integrate_multi_inline<1, true, FLAT, false, MASKS, C> (C = patch classification, decided per launch)"
+        ksub = "integrate_multi_inline<"
 
+    traffic, traffic_note = None, "not measured (--no-traffic)"
+    if not args.no_traffic and world == 1 and args.emulate_world <= 1:
+        # the child launches what the timed region launched: single frames, or passes of the same number of frames
+        traffic, traffic_note = measure_traffic(args, ksub, 6 if fpl == 1 else 2 * int(round(K / (launches / repeats))))
+
+    mode_desc = ("one kernel launch per step (tsdf_integrate_device per frame: the reference's TSDF::Integrate call shape)" if fpl == 1
+                 else f"tsdf_integrate_frames_device, up to {fpl} frames per pass over the volume")
     line = {
-        "metric": f"Mvoxels/sec integrated, {D}\u00b3 grid @ 640\u00d7480 depth; achieved HBM GB/s %peak",   # BASELINE.json
-        "value": round((n_global if args.emulate_world <= 1 else n_slab) * args.steps / wall / 1e6, 1),
+        "metric": f"Mvoxels/sec integrated, {D}³ grid @ 640×480 depth; achieved HBM GB/s %peak",   # BASELINE.json
+        "value": round((n_global if args.emulate_world <= 1 else n_slab) * timed_steps / wall / 1e6, 1),
         "unit": "Mvoxels/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(wall / args.steps * 1e3, 5),
+        "n_gpus": world, "steps": K, "warmup": args.warmup,
+        "ms_per_step": round(wall / timed_steps * 1e3, 5),
         "higher_is_better": True,
         "scaling": args.scaling,
-        "vs_baseline": None,
+        "vs_baseline": None,            # the reference publishes no number for this metric
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"{args.workload} {dims[0]}x{dims[1]}x{dims[2]} @ {vs * 1000:g} mm, 640x480 depth resident in HBM, "
-                               f"{'every voxel updated every frame' if args.workload == 'sfull' else 'sphere+wall orbit'}",
-                   "grid": list(dims), "voxel_size_m": vs, "image": [H, W],
+        "config": {"workload": f"{args.workload} {dims[0]}x{dims[1]}x{dims[2]} @ {vs * 1000:g} mm, 640x480 depth resident in HBM: "
+                               f"{W.desc}; {mode_desc}",
+                   "grid": list(dims), "voxel_size_m": vs, "image": [H, Wd], "trunc_margin_m": float(cfg.trunc_margin),
                    "partition": f"{world} z-slab(s) of {ze - zb} slices ({n_slab} voxels), one per GPU"
                                 + (f"; {args.scaling} scaling from the {D}^3 grid of N = 1" if world > 1 else ""),
-                   "kernel_variant": args.variant},
-        # roofline.achieved follows the contract to the letter: SURVEY.md section 8(d)'s per-unit figure (16 B per
-        # voxel updated: TSDF + weight, read + write, plus one pass over the depth frame) x the units one launch
-        # processes / the launch duration.  The kernel provably moves far fewer bytes (bit-identical results), so
-        # the figure exceeds the HBM peak; "physical" prices the same launches by the bytes that really move.
-        "roofline": {"bound": "hbm", "achieved": round(achieved_survey, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved_survey / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "kernel": ("tsdfk::integrate_multi_inline<1,true,false,false,false,C>, C = patch classification, decided "
-                                "per launch from the previous launch's claims (DESIGN.md section 4)") if fused else
-                               ("tsdfk::integrate_tile<2,true,true,false,true,false,true>" if v == 3 else f"variant {v}"),
-                     "frames_per_launch": fpl, "launches": launches,
-                     "kernel_ms": round(kernel_ms, 5),
-                     "algorithmic_bytes_per_launch": int(bytes_survey),
-                     "algorithmic_bytes_per_unit": 16,
-                     "units_per_launch": int(n_upd_per_frame * (fpl if full else rem)),
-                     "unit_name": "voxel updated by one frame (SURVEY.md section 8d: 4 B TSDF + 4 B weight, read and written)",
-                     "frac_above_one": "the launch applies frames_per_launch frames to voxels held in registers, the free-space "
-                                       "summary elides TSDF traffic whose result is provably unchanged, and workgroups whose "
-                                       "whole patch a depth tile table proves free space (this input: all of them) or "
-                                       "untouched are updated without projecting a voxel -- bit-identical results, so the "
-                                       "16 B per update of the model do not move (traffic = PMC bytes per launch); "
-                                       "per_voxel_kernel is the same input with that classification off",
-                     "physical": {"bytes_per_launch": int(bytes_per_launch), "achieved": round(achieved, 1),
-                                  "frac": round(achieved / HBM_PEAK_GBS, 4), "unit": "GB/s",
-                                  "voxels_touched_per_launch": int(n_touched),
-                                  "tsdf_values_read_per_launch": int(n_t_read),
-                                  "tsdf_values_written_per_launch": int(n_t_written),
-                                  "tsdf_counts": count_note,
-                                  "bytes_model": "per launch: 8 B per voxel touched (weight r+w) + 4 B per TSDF value read + "
-                                                 "4 B per TSDF value written + 4 B per 256-voxel summary word + "
-                                                 "frames_per_launch * (4*H*W + 100)"},
+                   "mode": args.mode, "kernel_variant": variant, "frames_per_launch": fpl},
+        "timing": {"timed_steps": timed_steps, "repeats": repeats, "timed_region_s": round(wall, 4),
+                   "kernel_s": round(kernel_ms_total * 1e-3, 4), "warmup_steps_run": n_warm + K,
+                   "note": f"the {K}-step sequence is repeated until >= {MIN_TIMED_MS / 1e3:g} s of device time; ms_per_step = "
+                           "wall / timed_steps between barrier + synchronize fences, max over ranks"},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None if traffic is None else int(traffic),
+                     "traffic_note": traffic_note,
+                     "traffic_over_algorithmic": None if traffic is None else round(traffic / alg_bytes, 4),
+                     "kernel": kname, "launches": launches, "kernel_ms": round(kernel_ms, 5),
+                     "algorithmic_bytes_per_launch": int(alg_bytes),
+                     "algorithmic_bytes_per_unit": 16, "units_per_launch": int(units_per_launch),
+                     "unit_name": unit_name, "bytes_model": bytes_model,
                      "voxel_updates_per_frame": int(n_upd_per_frame),
-                     "binding_resource": "instruction issue (VALU + scalar unit), profiles/r01_sfull512_sq_counters.json; "
-                                         "see streaming_variant for the access pattern's HBM rate when all 16 B move",
-                     "note": "per-rank slab launch; kernel_ms = HIP-event time of the timed region / launches"},
+                     "note": "per-rank slab launch; kernel_ms = HIP-event time of the timed region (events on the handle's "
+                             "stream) / launches; achieved = algorithmic_bytes_per_launch / kernel_ms"},
     }
-    if world == 1 and args.variant == 0 and args.emulate_world <= 1 and not args.no_extras:
-        # The same workload through the plain streaming variant (no elision, no summary: all 16 B per
-        # updated voxel really move).  This is the kernel to read as "how close to the HBM roofline
-        # does the access pattern get"; the default kernel above is faster because it moves fewer bytes.
-        vol.set_kernel_variant(17)
+    if extraction is not None:
+        line["extraction"] = extraction
+    extras = world == 1 and args.emulate_world <= 1 and not args.no_extras
+
+    def timed_leg(v, start_warm, n_warm_, n_block, min_ms=150.0):
+        """warm-up, then n_block-step blocks until min_ms of device time; returns (ms per step, steps timed)."""
+        run_block(v, start_warm, n_warm_)
+        tot, steps, pos = 0.0, 0, start_warm + n_warm_
+        while tot < min_ms and steps < 100000:
+            tot += run_block(v, pos, n_block)
+            pos += n_block
+            steps += n_block
+        return tot / steps, steps
+
+    if extras and args.variant < 0:
+        # The same workload through the other mode: what holding the voxels in registers over 32 frames buys / what one
+        # launch per frame costs.  Bit-identical results either way (tests/test_gpu_multiframe.py).
+        other = 0 if fpl == 1 else 3
+        vol.set_kernel_variant(other)
         vol.reset()
-        vol.integrate_sequence_timed(d_dev.data_ptr(), pose_block(0, 10))
-        n_s = min(args.steps, 200)
-        ms_s = vol.integrate_sequence_timed(d_dev.data_ptr(), pose_block(10, n_s)) / n_s
-        _, w_s = vol.download()
-        upd_s = float(w_s.astype(np.float64).sum()) / (10 + n_s)
-        del w_s
-        b_s = 16.0 * upd_s + 4.0 * H * W + 100.0
-        line["roofline"]["streaming_variant"] = {
-            "kernel": "tsdfk::integrate_tile<R=1,NT> (variant 17): 16 B per updated voxel, nothing elided",
-            "kernel_ms": round(ms_s, 5), "bytes_per_launch": int(b_s),
-            "achieved": round(b_s / (ms_s * 1e-3) / 1e9, 1), "frac": round(b_s / (ms_s * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "value": round(n_global / ms_s / 1e3, 1), "unit": "GB/s (value: Mvoxels/s)"}
-        vol.set_kernel_variant(0)
+        ofpl = vol.frames_per_launch
+        ms_o, n_o = timed_leg(vol, 0, max(2 * ofpl, 8), 2 * ofpl if ofpl > 1 else 32)
+        rec = {"mode": "fused" if ofpl > 1 else "frame", "frames_per_launch": ofpl, "ms_per_step": round(ms_o, 5),
+               "value": round(n_global / ms_o / 1e3, 1), "unit": "Mvoxels/s", "steps_timed": n_o}
+        if ofpl > 1 and W.full_coverage:
+            b = 16.0 * n_slab + ofpl * frame_bytes
+            rec["roofline"] = {
+                "bound": "valu_issue", "hbm_bytes_per_launch": int(b), "kernel_ms": round(ms_o * ofpl, 5),
+                "hbm_achieved_GBps": round(b / (ms_o * ofpl * 1e-3) / 1e9, 1),
+                "hbm_frac": round(b / (ms_o * ofpl * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "note": f"each voxel is read and written once per {ofpl} frames, so HBM is far from binding; the launch is bound by "
+                        "VALU instruction issue (the exact projection, the reference's two divisions per update, eight compares per "
+                        "voxel-frame: SQ counters and the per-instruction issue costs in profiles/ and DESIGN.md section 4)"}
+        line["fused_sequence" if ofpl > 1 else "per_frame_launches"] = rec
+        vol.set_kernel_variant(variant)
         vol.reset()
-    if world == 1 and args.emulate_world <= 1 and not args.no_extras:
-        # PCIe-inclusive rate of the reference-style call (tsdf_integrate: host depth pointer, staged
-        # through the pinned ring, 1.2 MB H2D per frame).  Reported beside the headline, never as it.
-        n_host = min(args.steps, 200)
+    if extras and args.workload == "sband" and args.variant < 0:
+        # S-full (SURVEY.md section 8d as written: every voxel updated with dist = 1).  The kernels prove that the TSDF value
+        # cannot change there (free space) and move only the weights, and the fused path's patch classification proves it per
+        # workgroup without projecting a voxel: rates of a different byte model, reported for continuity with round 1.
+        Wf = Workload("sfull", dims, vs)
+        with capi.Volume(capi.make_config(dims, vs, Wf.origin, device=local_rank)) as fv:
+            f_dev = torch.from_numpy(Wf.depths[0]).cuda()
+            def fblock(v, start, n):
+                return v.integrate_sequence_timed(f_dev.data_ptr(), Wf.block(start, n)[0])
+            res = {}
+            for tag, var, nb in (("per_frame_launches", 3, 32), ("fused_classified", 0, 64), ("fused_per_voxel", 7, 64)):
+                fv.set_kernel_variant(var)
+                fv.reset()
+                fblock(fv, 0, 64)
+                tot, steps = 0.0, 0
+                while tot < 100.0:
+                    tot += fblock(fv, 64 + steps, nb)
+                    steps += nb
+                res[tag] = {"ms_per_step": round(tot / steps, 5), "value": round(n_global / (tot / steps) / 1e3, 1), "unit": "Mvoxels/s"}
+            res["per_frame_launches"]["hbm_GBps_at_8B_per_voxel"] = round(8.0 * n_global / res["per_frame_launches"]["ms_per_step"] / 1e6, 1)
+            res["note"] = ("free space: the TSDF value provably stays 1, so one launch per frame moves 8 B per voxel (weights), the fused "
+                           "path moves them once per 32 frames, and with the patch classification (variant 0) no voxel is projected at all")
+            line["sfull"] = res
+            del f_dev
+    if extras and args.workload in ("sband", "sfull"):
+        # The realistic workload of SURVEY.md section 8(d): sphere + wall, orbit of 64 poses, depth re-rendered per pose
+        # (64 frames resident in HBM), through the sequence path.
+        Ws = Workload("ssurf", dims, vs)
+        with capi.Volume(capi.make_config(dims, vs, Ws.origin, device=local_rank)) as sv_:
+            s_dev = [torch.from_numpy(d).cuda() for d in Ws.depths]
+            def sblock(start, n):
+                poses, idx = Ws.block(start, n)
+                return sv_.integrate_frames_timed([s_dev[i].data_ptr() for i in idx], poses)
+            sblock(0, 64)
+            tot, steps = 0.0, 0
+            while tot < 150.0:
+                tot += sblock(64 + steps, 64)
+                steps += 64
+            _, w_r = sv_.download()
+            upd_r = float(w_r.astype(np.float64).sum()) / (64 + steps)
+            del w_r, s_dev
+        ms_r = tot / steps
+        line["realistic_workload"] = {
+            "workload": f"ssurf {dims[0]}x{dims[1]}x{dims[2]} @ {vs * 1000:g} mm: {Ws.desc}; fused sequence path",
+            "ms_per_step": round(ms_r, 5), "value": round(n_global / ms_r / 1e3, 1), "unit": "Mvoxels/s",
+            "updated_fraction": round(upd_r / n_global, 4), "frames": steps,
+            "algorithmic_GBps_at_16B_per_update": round((16.0 * upd_r + frame_bytes) / (ms_r * 1e-3) / 1e9, 1)}
+    if extras and len(W.depths) == 1:
+        # PCIe-inclusive rate of the reference-style call (tsdf_integrate: host depth pointer, staged through the pinned
+        # ring, 1.2 MB H2D per frame).  Reported beside the headline, never as it.
+        n_host = 200
         vol.sync()
         t1 = time.perf_counter()
         for k in range(n_host):
-            vol.integrate(depth, poses[k % n_pose])
+            vol.integrate(W.depths[0], W.poses[k % W.n_pose])
         vol.sync()
         dt = time.perf_counter() - t1
         line["host_depth_path"] = {"ms_per_step": round(dt / n_host * 1e3, 5),
                                    "value": round(n_global * n_host / dt / 1e6, 1), "unit": "Mvoxels/s",
                                    "note": "tsdf_integrate with a host depth pointer: memcpy to pinned staging + "
                                            "H2D copy + kernel per frame, Python ctypes call overhead included"}
-    if world == 1 and args.emulate_world <= 1 and args.variant == 0 and not args.no_extras:
-        # The same workload with the patch classification switched off (variant 7): every voxel of every frame is
-        # projected and tested.  On S-full the default's advantage is a property of the input (the whole volume is
-        # free space in front of a constant depth); this is the rate of the per-voxel kernel itself.
-        vol.set_kernel_variant(7)
-        vol.reset()
-        n_w, n_t = vol.frames_per_launch, 10 * vol.frames_per_launch
-        vol.integrate_sequence_timed(d_dev.data_ptr(), pose_block(0, n_w))
-        ms_p = vol.integrate_sequence_timed(d_dev.data_ptr(), pose_block(n_w, n_t)) / n_t
-        line["per_voxel_kernel"] = {"kernel_variant": 7, "ms_per_step": round(ms_p, 5), "value": round(n_global / ms_p / 1e3, 1),
-                                    "unit": "Mvoxels/s", "frames": n_t,
-                                    "note": "patch classification off: every voxel of every frame projected, sampled and tested"}
-        vol.set_kernel_variant(0)
-        vol.reset()
-    if world == 1 and args.emulate_world <= 1 and args.variant == 0 and args.workload == "sfull" and not args.no_extras:
-        # The same grid and kernel on the realistic workload of SURVEY.md section 8(d) (S-surf: a sphere in front of
-        # a wall seen from an orbit, uint16-quantised depth): only part of the volume is updated per frame and the
-        # TSDF values near the surfaces really change, so nothing about it is "all ones".
-        s_origin = synth.surf_volume(max(dims), vs, 1.0)
-        scene = synth.SurfScene(dims, vs, s_origin)
-        s_poses = np.stack([scene.pose(k, 64) for k in range(64)])
-        s_depth = torch.from_numpy(scene.depth(s_poses[0], quantize=True)).cuda()
-        with capi.Volume(capi.make_config(dims, vs, s_origin, device=local_rank)) as sv:
-            n_w, n_t = 2 * sv.frames_per_launch, 10 * sv.frames_per_launch
-            sv.integrate_sequence_timed(s_depth.data_ptr(), np.stack([s_poses[i % 64] for i in range(n_w)]))
-            ms_r = sv.integrate_sequence_timed(s_depth.data_ptr(), np.stack([s_poses[(n_w + i) % 64] for i in range(n_t)])) / n_t
-            _, w_r = sv.download()
-        upd_r = float(w_r.astype(np.float64).sum()) / (n_w + n_t)
-        del w_r
-        line["realistic_workload"] = {
-            "workload": f"ssurf {dims[0]}x{dims[1]}x{dims[2]} @ {vs * 1000:g} mm (sphere + wall, orbit of 64 poses, depth quantised at 1/5000 m)",
-            "ms_per_step": round(ms_r, 5), "value": round(n_global / ms_r / 1e3, 1), "unit": "Mvoxels/s",
-            "updated_fraction": round(upd_r / n_global, 4), "frames": n_t,
-            "algorithmic_GBps": round((16.0 * upd_r + 4.0 * H * W + 100.0) / (ms_r * 1e-3) / 1e9, 1)}
     if not args.no_cpu_baseline and world == 1 and args.emulate_world <= 1:
-        per_slice = D * D if args.workload == "sfull" else None
-        base, ref = cpu_baseline(args, dims, vs, origin, cfg, depth, poses, per_slice)
+        base, ref = cpu_baseline(args, W, cfg.cam_K, float(cfg.trunc_margin))
         line["cpu_baseline"] = base
         if ref is not None:
             line["cpu_reference"] = ref

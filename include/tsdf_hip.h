@@ -261,6 +261,13 @@ int tsdf_integrate_sequence_timed(tsdf_volume *vol, const float *depth_dev, cons
                                   int32_t n_frames, float *elapsed_ms);
 
 /*
+ * The same for a sequence whose frames each bring their own depth image (and optional instance mask): exactly
+ * tsdf_integrate_frames_device, bracketed by HIP events on the handle's stream.  Synchronous.
+ */
+int tsdf_integrate_frames_timed(tsdf_volume *vol, const float *const *depth_dev, const uint8_t *const *masks_dev,
+                                const float *cam2world, int32_t n_frames, float *elapsed_ms);
+
+/*
  * Ceiling probe: n_iters passes of a bare 16 B/voxel read-modify-write stream over the slab
  * (values unchanged), timed with HIP events.  non_temporal selects nt loads/stores.
  */

@@ -5,7 +5,8 @@ and bench.py's cpu_baseline leg.  Nothing under semantic_slam_amd/ imports this 
 
 `Oracle` wraps this project's CPU restatement (tsdf_oracle.c; each C function cites the
 reference lines it follows).  `Ref` wraps the reference's own kernel body compiled for the
-host from /root/reference/src/tsdf.cu:15-60 (`make -C oracle ref`), when that build exists.
+host from /root/reference/src/tsdf.cu:15-60 (`make -C oracle ref`), when that build exists;
+`RefHip` wraps the same function compiled by hipcc for gfx950 as it stands (`make -C oracle ref_hip`).
 """
 import ctypes as C
 import os
@@ -21,7 +22,7 @@ def build(ref=True):
     """Compile the checker.  The reference body is only buildable where /root/reference exists."""
     subprocess.check_call(["make", "-s", "-C", _HERE])
     if ref and os.path.isfile("/root/reference/src/tsdf.cu"):
-        subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+        subprocess.check_call(["make", "-s", "-C", _HERE, "ref", "ref_hip"])
 
 
 def _f32(a):
@@ -236,3 +237,29 @@ class Ref:
 
     def max_threads(self):
         return int(self.lib.ref_max_threads())
+
+
+class RefHip:
+    """The reference's own GpuIntegrate compiled for gfx950 by hipcc exactly as it stands
+    (`make -C oracle ref_hip`: no stand-in for anything) and launched with the reference's shape
+    <<<dim_z, dim_y>>> on the GPU.  Device pointers in, device arrays updated in place; whole grid
+    only, dim_y <= 1024 (the reference's block size), max depth fixed at 6 m (tsdf.cu:46)."""
+
+    path = os.path.join(_HERE, "_ref", "libtsdf_ref_hip.so")
+
+    @classmethod
+    def available(cls):
+        return os.path.isfile(cls.path)
+
+    def __init__(self):
+        L = self.lib = C.CDLL(self.path)
+        vp = C.c_void_p
+        L.ref_hip_integrate.restype = C.c_int
+        L.ref_hip_integrate.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp]
+
+    def integrate(self, K_ptr, cam2base_ptr, depth_ptr, h, w, dims, origin, voxel_size, trunc, tsdf_ptr, weight_ptr):
+        dx, dy, dz = dims
+        rc = self.lib.ref_hip_integrate(K_ptr, cam2base_ptr, depth_ptr, h, w, dx, dy, dz, origin[0], origin[1],
+                                        origin[2], voxel_size, trunc, tsdf_ptr, weight_ptr)
+        assert rc == 0, f"reference kernel launch failed ({rc})"

@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "tsdf_sync", "tsdf_download", "tsdf_copy_slices", "tsdf_upload", "tsdf_refresh_summary", "tsdf_device_ptrs", "tsdf_slab_voxels", "tsdf_frames_per_launch", "tsdf_shortcut_stats", "tsdf_classification_info",
     "tsdf_get_config", "tsdf_last_cam2base", "tsdf_set_stream", "tsdf_get_stream",
     "tsdf_count_surface", "tsdf_extract_surface", "tsdf_extract_crossings", "tsdf_extract_mesh", "tsdf_save_mesh_ply", "tsdf_save_ply", "tsdf_save_bin", "tsdf_load_bin", "tsdf_save_state", "tsdf_load_state",
-    "tsdf_integrate_sequence_timed", "tsdf_probe_stream", "tsdf_selftest_fastdiv", "tsdf_selftest_round", "tsdf_set_kernel_variant", "tsdf_last_error",
+    "tsdf_integrate_sequence_timed", "tsdf_integrate_frames_timed", "tsdf_probe_stream", "tsdf_selftest_fastdiv", "tsdf_selftest_round", "tsdf_set_kernel_variant", "tsdf_last_error",
     "tsdf_version", "tsdf_multiply_matrix", "tsdf_invert_matrix",
     "tsdf_labels_enable", "tsdf_compose_labels", "tsdf_integrate_labels_device", "tsdf_integrate_frames_labels_device",
     "tsdf_download_labels",
@@ -98,6 +98,7 @@ def load():
     L.tsdf_save_state.argtypes = [vp, C.c_char_p]
     L.tsdf_load_state.argtypes = [vp, C.c_char_p]
     L.tsdf_integrate_sequence_timed.argtypes = [vp, vp, vp, C.c_int32, f32p]
+    L.tsdf_integrate_frames_timed.argtypes = [vp, vp, vp, vp, C.c_int32, f32p]
     L.tsdf_probe_stream.argtypes = [vp, C.c_int32, C.c_int32, f32p]
     L.tsdf_selftest_fastdiv.argtypes = [C.c_int32, C.c_uint64, C.c_uint64, C.c_float, C.c_float, C.POINTER(C.c_uint64), f32p]
     L.tsdf_selftest_round.argtypes = [C.c_int32, C.POINTER(C.c_uint64), f32p]
@@ -321,6 +322,20 @@ class Volume:
         ms = C.c_float()
         check(self.lib.tsdf_integrate_sequence_timed(self._h, depth_ptr, p.ctypes.data, n, C.byref(ms)),
               "tsdf_integrate_sequence_timed")
+        return ms.value
+
+    def integrate_frames_timed(self, depth_ptrs, poses, mask_ptrs=None):
+        """integrate_frames_device bracketed by HIP events on the handle's stream; returns device milliseconds."""
+        p = _f32(np.asarray(poses, dtype=np.float32))
+        n = p.size // 16
+        assert len(depth_ptrs) == n
+        d = (C.c_void_p * n)(*[C.c_void_p(x) for x in depth_ptrs])
+        m = None
+        if mask_ptrs is not None:
+            m = (C.c_void_p * n)(*[C.c_void_p(x) if x else C.c_void_p() for x in mask_ptrs])
+        ms = C.c_float()
+        check(self.lib.tsdf_integrate_frames_timed(self._h, d, m, p.ctypes.data, n, C.byref(ms)),
+              "tsdf_integrate_frames_timed")
         return ms.value
 
     def probe_stream(self, non_temporal=False, iters=20):

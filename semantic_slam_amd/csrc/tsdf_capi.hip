@@ -1092,21 +1092,16 @@ int tsdf_probe_stream(tsdf_volume *v, int32_t non_temporal, int32_t n_iters, flo
     return TSDF_OK;
 }
 
-int tsdf_integrate_sequence_timed(tsdf_volume *v, const float *depth_dev, const float *cam2world,
-                                  int32_t n_frames, float *elapsed_ms)
+static int frames_timed(tsdf_volume *v, const float *const *depth_dev, const uint8_t *const *masks_dev,
+                        const float *cam2world, int32_t n_frames, float *elapsed_ms, const char *who)
 {
-    if (!v || !depth_dev || !cam2world || n_frames <= 0 || !elapsed_ms)
-        return fail(TSDF_ERR_INVALID, "tsdf_integrate_sequence_timed: bad argument");
     int rc = bind_device(v);
     if (rc) return rc;
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, v->stream));
-    {
-        std::vector<const float *> depths((size_t)n_frames, depth_dev);
-        rc = integrate_frames(v, depths.data(), nullptr, cam2world, n_frames);
-    }
+    rc = integrate_frames(v, depth_dev, masks_dev, cam2world, n_frames);
     hipError_t er = hipEventRecord(e1, v->stream);
     hipError_t es = hipEventSynchronize(e1);
     float ms = 0.f;
@@ -1115,9 +1110,28 @@ int tsdf_integrate_sequence_timed(tsdf_volume *v, const float *depth_dev, const 
     (void)hipEventDestroy(e1);
     if (rc) return rc;
     if (er != hipSuccess || es != hipSuccess || et != hipSuccess)
-        return fail(TSDF_ERR_HIP, "tsdf_integrate_sequence_timed: event timing failed");
+        return fail(TSDF_ERR_HIP, "%s: event timing failed", who);
     *elapsed_ms = ms;
     return TSDF_OK;
+}
+
+int tsdf_integrate_sequence_timed(tsdf_volume *v, const float *depth_dev, const float *cam2world,
+                                  int32_t n_frames, float *elapsed_ms)
+{
+    if (!v || !depth_dev || !cam2world || n_frames <= 0 || !elapsed_ms)
+        return fail(TSDF_ERR_INVALID, "tsdf_integrate_sequence_timed: bad argument");
+    std::vector<const float *> depths((size_t)n_frames, depth_dev);
+    return frames_timed(v, depths.data(), nullptr, cam2world, n_frames, elapsed_ms, "tsdf_integrate_sequence_timed");
+}
+
+int tsdf_integrate_frames_timed(tsdf_volume *v, const float *const *depth_dev, const uint8_t *const *masks_dev,
+                                const float *cam2world, int32_t n_frames, float *elapsed_ms)
+{
+    if (!v || !depth_dev || !cam2world || n_frames <= 0 || !elapsed_ms)
+        return fail(TSDF_ERR_INVALID, "tsdf_integrate_frames_timed: bad argument");
+    for (int k = 0; k < n_frames; ++k)
+        if (!depth_dev[k]) return fail(TSDF_ERR_INVALID, "tsdf_integrate_frames_timed: depth_dev[%d] is NULL", k);
+    return frames_timed(v, depth_dev, masks_dev, cam2world, n_frames, elapsed_ms, "tsdf_integrate_frames_timed");
 }
 
 // ---------------------------------------------------------------------------------------------

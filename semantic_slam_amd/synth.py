@@ -8,6 +8,10 @@ fixes:
   camera (include/tsdf.hpp:96 in the reference), the depth is a constant 5.9 m (inside the
   6 m cut-off of src/tsdf.cu:46 and behind the far face), so every voxel passes every test
   and is updated every frame: algorithmic bytes = 16 B x voxels.
+* S-band -- S-full's geometry with a truncation margin of 4 m and a camera that also wobbles along its
+  axis: every voxel is updated every frame AND lies inside the truncation band, so dist < 1, both
+  divisions run and every TSDF value changes every frame -- nothing about the update can be elided,
+  all 16 B per voxel have to move.  The workload the HBM-roofline fraction is quoted on.
 * S-surf -- a sphere in front of a back wall seen from an orbit, optional uint16
   quantisation at the TUM depth factor 5000 (config/TUM3.yaml:34): a realistic mix of
   updated, truncated and out-of-frustum voxels.
@@ -75,6 +79,32 @@ def sfull_pose(k):
     """Frame k: roll about the optical axis by 0.04 sin(0.1 k) rad, shift (sin k, cos k, 0) mm."""
     return make_pose(rot_z(0.04 * math.sin(0.1 * k)),
                      [1e-3 * math.sin(k), 1e-3 * math.cos(k), 0.0])
+
+
+# --------------------------------------------------------------------------------------
+# S-band
+# --------------------------------------------------------------------------------------
+SBAND_TRUNC = 4.0     # metres: wider than the deepest diff (5.9 - 3.16 = 2.74 m), so fmin(1, diff/trunc) < 1 everywhere
+SBAND_WOBBLE_Z = 0.04  # metres along the optical axis
+
+
+def sband_volume(dim, voxel_size):
+    """S-full's volume; checks that it also stays inside the frustum and in front of the constant depth when
+    the camera moves SBAND_WOBBLE_Z along its axis."""
+    origin = sfull_volume(dim, voxel_size)
+    dx, dy, dz = (dim, dim, dim) if np.isscalar(dim) else dim
+    half = max(dx, dy) * voxel_size / 2.0 * (math.cos(0.04) + math.sin(0.04)) + 1e-3
+    assert (SFULL_Z0 - SBAND_WOBBLE_Z) * 0.4301 > half, "volume leaves the frustum when the camera moves forward"
+    assert SFULL_Z0 + dz * voxel_size + SBAND_WOBBLE_Z < SFULL_DEPTH, "far face reaches the constant depth"
+    assert SFULL_DEPTH - (SFULL_Z0 - SBAND_WOBBLE_Z) < SBAND_TRUNC, "nearest voxel outside the truncation band"
+    return origin
+
+
+def sband_pose(k):
+    """Frame k: S-full's roll and in-plane shift plus 4 cm sin(0.37 k) along the optical axis, so the distance
+    of every voxel to the constant-depth surface -- and with it its TSDF value -- changes from frame to frame."""
+    return make_pose(rot_z(0.04 * math.sin(0.1 * k)),
+                     [1e-3 * math.sin(k), 1e-3 * math.cos(k), SBAND_WOBBLE_Z * math.sin(0.37 * k)])
 
 
 # --------------------------------------------------------------------------------------

@@ -73,7 +73,8 @@ def worker(rank, world, port, q):
         assert (vol.z_begin, vol.z_end) == slab_range(DIMS[2], rank, world)
         for pose, depth in frames():
             vol.integrate(depth, pose)
-        ht, hw = vol.halo_exchange()
+        halo = vol.halo_exchange()
+        ht, hw = halo if halo is not None else (None, None)
         t, w = vol.gather(dst=0)
         pts = vol.gather_surface(dst=0)
         xing = vol.gather_crossings(dst=0)

@@ -32,3 +32,23 @@ def test_surf_scene_mixes_branches(oracle):
     assert 0.05 * t.size < n < 0.9 * t.size
     assert np.count_nonzero(t < 1.0) > 100 and t.min() < 0.0   # inside the truncation band on both sides
     assert np.allclose(sc.pose(0), sc.pose(64), atol=1e-6)     # orbit is periodic
+
+
+@pytest.mark.parametrize("D,vs", [(512, 0.005), (1024, 0.002)])
+def test_sband_updates_every_voxel_inside_the_band(oracle, D, vs):
+    """S-band: N_upd == N, every dist < 1 (inside the truncation band), and the TSDF values keep changing from
+    frame to frame -- no update of it can be elided.  Slab samples at both ends of the z range."""
+    origin = synth.sband_volume(D, vs)
+    depth = synth.sfull_depth()
+    for zb in (0, D - 2):
+        t, w = oracle.init_grid((D, D, D), zb, zb + 2)
+        prev = t.copy()
+        for i, k in enumerate((0, 4, 15, 16, 47)):   # largest roll, both signs of the axial wobble
+            n = oracle.integrate(synth.TUM_K, synth.sband_pose(k), depth, (D, D, D), origin, vs, synth.SBAND_TRUNC,
+                                 t, w, z_begin=zb, z_end=zb + 2)
+            assert n == 2 * D * D
+            assert t.max() < 1.0 and t.min() > 0.0
+            if i > 0:   # the first frame sets dist itself; every later one moves (almost) every value
+                assert np.count_nonzero(t.view(np.uint32) != prev.view(np.uint32)) > 0.99 * t.size
+            prev = t.copy()
+        assert np.all(w == 5.0)
