@@ -235,7 +235,8 @@ int tsdf_save_mesh_ply(tsdf_volume *vol, const char *path, float weight_thresh);
  * 170-218).  For a slab handle the .bin header carries the slab's dims and a z-shifted
  * origin is NOT applied: callers that shard gather slabs in z order first (see
  * semantic_slam_amd/sharded.py); a whole-grid handle writes exactly the reference's files.
- *   .ply: binary_little_endian points with |tsdf| != 0 and weight > weight_thresh (0.9 in the ref)
+ *   .ply: binary_little_endian points with |tsdf| != 0 and weight > weight_thresh (0.9 in the ref); the reference
+ *         prints the vertex count with %d, so more than 2^31 - 1 points cannot be represented: TSDF_ERR_INVALID
  *   .bin: 8-float header {dim_x, dim_y, dim_z, origin xyz, voxel_size, trunc} + TSDF floats
  */
 int tsdf_save_ply(tsdf_volume *vol, const char *path, float weight_thresh);
@@ -329,7 +330,12 @@ int tsdf_download_labels(tsdf_volume *vol, uint16_t *label_host, float *fp_host,
  * Grid origin of a new object volume from its first (masked) depth frame, on the device: the per-axis
  * minimum over pixels with depth > 0 of the back-projected point, starting from 1000 -- what
  * Object::Object computes on the host before it constructs its TSDF (ref: src/Object.cpp:37-49, with the
- * instance mask of ref: src/Engine.cpp:192-193; mask_dev may be NULL).  Bit-identical to that loop.
+ * instance mask of ref: src/Engine.cpp:192-193; mask_dev may be NULL).  Bit-identical to that loop for every
+ * frame without NaN samples (a minimum is order-independent); with NaN samples the reference's running std::min
+ * depends on the raster order (a NaN replaces the minimum, the next valid pixel replaces the NaN) whereas this
+ * reduction ignores them.  The call waits for all work queued on the device (whatever stream produced depth_dev,
+ * e.g. tsdf_convert_depth_u16 on a handle's stream) before it reads the frame, and returns when the result is on
+ * the host.
  */
 int tsdf_object_origin(int32_t device, const float *depth_dev, const uint8_t *mask_dev, int32_t im_height,
                        int32_t im_width, const float cam_K[9], float origin_out[3]);

@@ -421,9 +421,10 @@ void oracle_object_origin(const float *depth, int rows, int cols, const float *K
             if (z <= 0.0) continue;
             float x = ((float)c - K[2]) * z * (1.0f / K[0]);
             float y = ((float)r - K[5]) * z * (1.0f / K[4]);
-            origin[0] = x < origin[0] ? x : origin[0];
-            origin[1] = y < origin[1] ? y : origin[1];
-            origin[2] = z < origin[2] ? z : origin[2];
+            /* std::min(x, origin) = (origin < x) ? origin : x -- src/Object.cpp:45-47 */
+            origin[0] = origin[0] < x ? origin[0] : x;
+            origin[1] = origin[1] < y ? origin[1] : y;
+            origin[2] = origin[2] < z ? origin[2] : z;
         }
 }
 

@@ -212,11 +212,6 @@ class Volume:
         self._h = C.c_void_p()
         if self._owned:
             check(self.lib.tsdf_create(C.byref(cfg), C.byref(self._h)), "tsdf_create")
-            # test-suite knob: run everything that does not pick a variant itself on another one
-            # (TSDF_DEFAULT_VARIANT=8 python -m pytest tests -m gpu: the whole suite with patch classification)
-            forced = os.environ.get("TSDF_DEFAULT_VARIANT")
-            if forced:
-                self.set_kernel_variant(int(forced))
         else:
             self._h = _borrowed_handle
 

@@ -101,6 +101,9 @@ struct tsdf_volume {
     // scratch for surface extraction (allocated on first use)
     void *d_scratch;
     size_t scratch_bytes;
+    // output list of the extraction passes (points / vertices / triangles), grown on demand and kept
+    void *d_list;
+    size_t list_bytes;
 };
 
 // Many volumes integrated by one launch per frame (include/tsdf_hip.h, tsdf_batch_*).
@@ -417,13 +420,20 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
             // workgroup-frames goes without (the tables and the prologue cost more than that saves), with a new probe
             // every eighth launch.  The count is read back asynchronously: a decision never waits for the GPU.
             if (v->claims_pending) {
-                if (hipEventQuery(v->claims_done) == hipSuccess) {
+                const hipError_t qe = hipEventQuery(v->claims_done);
+                if (qe == hipSuccess) {
                     const unsigned long long w = *v->h_claims;
                     v->claim_fraction = v->claims_total > 0 ? (double)((w >> 32) + (w & 0xffffffffull)) / v->claims_total : 0.0;
                     v->claims_pending = false;
                     v->claims_known = true;
-                } else {
+                } else if (qe == hipErrorNotReady) {
                     (void)hipGetLastError();   // "not ready" is an answer, not an error to be found by a later check
+                } else {
+                    // a real failure: forget the stale count (the next launch classifies and counts afresh) and report it
+                    v->claims_pending = false;
+                    v->claims_known = false;
+                    (void)hipGetLastError();
+                    return fail(TSDF_ERR_HIP, "claims read-back: hipEventQuery failed: %s", hipGetErrorString(qe));
                 }
             }
             bool classify = (int64_t)mi.common.tiles_w * mi.common.tiles_h <= 8192 && v->variant != 7;
@@ -563,6 +573,17 @@ int fill(tsdf_volume *v)
     return TSDF_OK;
 }
 
+int ensure_list(tsdf_volume *v, size_t bytes)
+{
+    if (v->list_bytes >= bytes) return TSDF_OK;
+    if (v->d_list) HIP_TRY(hipFree(v->d_list));
+    v->d_list = nullptr;
+    v->list_bytes = 0;
+    HIP_TRY(hipMalloc(&v->d_list, bytes));
+    v->list_bytes = bytes;
+    return TSDF_OK;
+}
+
 int ensure_scratch(tsdf_volume *v, size_t bytes)
 {
     if (v->scratch_bytes >= bytes) return TSDF_OK;
@@ -696,6 +717,7 @@ int tsdf_destroy(tsdf_volume *v)
     if (v->d_fp) (void)hipFree(v->d_fp);
     if (v->d_bp) (void)hipFree(v->d_bp);
     if (v->d_scratch) (void)hipFree(v->d_scratch);
+    if (v->d_list) (void)hipFree(v->d_list);
     if (v->d_flags) (void)hipFree(v->d_flags);
     if (v->d_tiles) (void)hipFree(v->d_tiles);
     if (v->d_claims) (void)hipFree(v->d_claims);
@@ -1025,6 +1047,8 @@ int tsdf_object_origin(int32_t device, const float *depth_dev, const uint8_t *ma
     if (!depth_dev || !cam_K || !origin_out || im_height <= 0 || im_width <= 0)
         return fail(TSDF_ERR_INVALID, "tsdf_object_origin: bad argument");
     HIP_TRY(hipSetDevice(device));
+    // the frame may have been produced on a handle's (non-blocking) stream, which the null stream does not order against
+    HIP_TRY(hipDeviceSynchronize());
     float *d_out = nullptr;
     const float init[3] = {1000.0f, 1000.0f, 1000.0f};   // ref: src/Object.cpp:37
     HIP_TRY(hipMalloc((void **)&d_out, sizeof init));
@@ -1378,8 +1402,9 @@ static int surface_pass(tsdf_volume *v, float weight_thresh, float *xyz_host, in
     if (!xyz_host || capacity <= 0 || total == 0) return TSDF_OK;
 
     int64_t n_out = total < capacity ? total : capacity;
-    float *d_xyz = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_xyz, (size_t)total * 3 * sizeof(float)));
+    rc = ensure_list(v, (size_t)total * 3 * sizeof(float));
+    if (rc) return rc;
+    float *d_xyz = (float *)v->d_list;
     const tsdf_config &c = v->cfg;
     hipLaunchKernelGGL(tsdfx::surface_emit, dim3((unsigned)n_chunks), dim3(256), 0, v->stream,
                        v->d_tsdf, v->d_weight, n, weight_thresh, d_offsets, c.dim_x, c.dim_y,
@@ -1388,7 +1413,6 @@ static int surface_pass(tsdf_volume *v, float weight_thresh, float *xyz_host, in
     if (e == hipSuccess)
         e = hipMemcpyAsync(xyz_host, d_xyz, (size_t)n_out * 3 * sizeof(float), hipMemcpyDeviceToHost, v->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(v->stream);
-    (void)hipFree(d_xyz);
     if (e != hipSuccess) return fail(TSDF_ERR_HIP, "surface extraction: %s", hipGetErrorString(e));
     return TSDF_OK;
 }
@@ -1452,15 +1476,15 @@ static int crossing_pass(tsdf_volume *v, const float *halo_tsdf, const float *ha
     *count = total;
     if (!xyz_host || capacity <= 0 || total == 0) return TSDF_OK;
     const int64_t n_out = total < capacity ? total : capacity;
-    float *d_xyz = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_xyz, (size_t)total * item_floats * sizeof(float)));
+    rc = ensure_list(v, (size_t)total * item_floats * sizeof(float));
+    if (rc) return rc;
+    float *d_xyz = (float *)v->d_list;
     if (mesh) hipLaunchKernelGGL(tsdfx::mesh_emit_kernel, dim3((unsigned)n_chunks), dim3(256), 0, v->stream, g, d_offsets, d_xyz);
     else hipLaunchKernelGGL(tsdfx::crossing_emit, dim3((unsigned)n_chunks), dim3(256), 0, v->stream, g, d_offsets, d_xyz);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess)
         e = hipMemcpyAsync(xyz_host, d_xyz, (size_t)n_out * item_floats * sizeof(float), hipMemcpyDeviceToHost, v->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(v->stream);
-    (void)hipFree(d_xyz);
     if (e != hipSuccess) return fail(TSDF_ERR_HIP, "zero crossings: %s", hipGetErrorString(e));
     return TSDF_OK;
 }
@@ -1514,6 +1538,8 @@ int tsdf_save_ply(tsdf_volume *v, const char *path, float weight_thresh)
     int64_t n = 0;
     int rc = surface_pass(v, weight_thresh, nullptr, 0, &n);
     if (rc) return rc;
+    if (n > 0x7fffffffll)   // the header's "element vertex %d" (ref: src/tsdf.cu:188) cannot hold it
+        return fail(TSDF_ERR_INVALID, "tsdf_save_ply: %lld surface points exceed the format's 2^31 - 1 (write slabs separately)", (long long)n);
     std::vector<float> xyz((size_t)(n > 0 ? n : 1) * 3);
     if (n > 0) {
         rc = surface_pass(v, weight_thresh, xyz.data(), n, &n);

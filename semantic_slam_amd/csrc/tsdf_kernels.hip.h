@@ -759,11 +759,14 @@ __global__ __launch_bounds__(256) void depth_u16_to_f32(const uint16_t *raw, flo
 // back-projected point x = (c - cx) * z * (1/fx), y = (r - cy) * z * (1/fy), z -- starting from 1000
 // (ref: Object::Object, src/Object.cpp:37-49; the mask is the instance mask of src/Engine.cpp:192-193).
 // A minimum does not depend on the order of evaluation, so the device result equals the host loop's bits.
-// out[3] must be initialised to 1000.0f; positive floats order like their bit patterns, negative ones
-// in reverse, hence the two atomics.
+// out[3] must be initialised to 1000.0f; floats with a clear sign bit order like their bit patterns, those with
+// the sign bit set in reverse, hence the two atomics -- chosen by the sign BIT, so that -0.0f (pattern INT_MIN)
+// does not take the signed-integer branch and displace a genuinely negative minimum.
+// NaN samples: the reference's running std::min lets a NaN replace the minimum and the next valid pixel replace
+// the NaN, i.e. its result depends on the raster order; this reduction ignores NaN samples (fminf drops them).
 __device__ __forceinline__ void atomic_min_float(float *addr, float v)
 {
-    if (v >= 0.0f) atomicMin(reinterpret_cast<int *>(addr), __float_as_int(v));
+    if (__float_as_int(v) >= 0) atomicMin(reinterpret_cast<int *>(addr), __float_as_int(v));
     else atomicMax(reinterpret_cast<unsigned int *>(addr), __float_as_uint(v));
 }
 

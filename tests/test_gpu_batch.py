@@ -80,3 +80,29 @@ def test_object_origin_on_device_equals_the_host_loop(cuda, oracle):
     assert np.array_equal(got.view(np.uint32), oracle.object_origin(depth, synth.TUM_K).view(np.uint32))
     zero = cuda.zeros((480, 640), dtype=cuda.float32, device="cuda")
     assert np.array_equal(capi.object_origin(zero.data_ptr(), None, 480, 640, synth.TUM_K), [1000, 1000, 1000])
+
+
+def test_object_origin_negative_zero_and_stream_order(cuda, oracle):
+    """A denormal depth left of the principal point back-projects to x = -0.0f, which the reference's running
+    std::min keeps against every positive x (src/Object.cpp:45: `origin < x ? origin : x`); on the device the
+    atomic must take its branch by the sign BIT (pattern 0x80000000 is INT_MIN as a signed integer).  Also: the
+    frame is produced on a handle's own (non-blocking) stream right before the call -- no tsdf_sync in between."""
+    depth = np.zeros((480, 640), np.float32)
+    depth[100:300, 400:600] = 1.5                      # right of cx, below... both x > 0 and mixed y
+    depth[200, 10] = 1e-45                             # denormal: (10 - 320.1) * 1e-45 underflows to -0.0
+    want = oracle.object_origin(depth, synth.TUM_K)
+    assert want.view(np.uint32)[0] == 0x80000000, "the case must produce x = -0.0 in the reference's loop"
+    raw = np.zeros((480, 640), np.uint16)
+    raw[100:300, 400:600] = 7500
+    with capi.Volume(capi.make_config((8, 8, 8), 0.01, [0, 0, 0])) as vol:
+        d_dev = cuda.from_numpy(depth).cuda()
+        got = capi.object_origin(d_dev.data_ptr(), None, 480, 640, synth.TUM_K)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        # conversion queued on the handle's stream, origin read immediately afterwards
+        r_dev = cuda.from_numpy(raw).cuda()
+        out = cuda.zeros((480, 640), dtype=cuda.float32, device="cuda")
+        cuda.cuda.synchronize()
+        vol.convert_depth_u16(r_dev.data_ptr(), out.data_ptr(), 5000.0, 1, 1)
+        got2 = capi.object_origin(out.data_ptr(), None, 480, 640, synth.TUM_K)
+        want2 = oracle.object_origin((raw.astype(np.float32) * (np.float32(1.0) / np.float32(5000.0))).astype(np.float32), synth.TUM_K)
+        assert np.array_equal(got2.view(np.uint32), want2.view(np.uint32)) and want2[2] == np.float32(1.5)

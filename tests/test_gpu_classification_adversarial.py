@@ -1,0 +1,150 @@
+"""Adversarial inputs for the patch classification (tsdf_multiframe.hip.h, classify_patch) at a scale where hundreds of
+workgroups classify: depth discontinuities exactly on the 16-pixel tile borders at the depths where a claim must
+stop, patches whose projected box touches the image borders +- the pixel margin, cameras whose distance puts the
+patch corners at the cz_short threshold, non-finite and invalid pixels inside otherwise claimable tiles.
+
+Every case runs the fused sequence path with the classification forced on (variant 8), decided per launch
+(variant 0) and forbidden (variant 7), and must equal the oracle bit for bit; with it forced on, claims must
+actually be made (counters), so the test is about claims that are right, not claims that are absent."""
+import numpy as np
+import pytest
+
+from semantic_slam_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+H, W = 480, 640
+GRIDS = [((256, 64, 32), 0.002), ((200, 120, 32), 0.0025)]   # row mapping (512 workgroups), flat mapping (750)
+
+
+def run_case(cuda, oracle, dims, vs, origin, K, frames, expect_claims=True, trunc=None):
+    """frames: [(cam2world, depth)].  Oracle once, then the three variants."""
+    cfg = capi.make_config(dims, vs, origin, K=K, trunc=trunc)
+    ref_t, ref_w = oracle.init_grid(dims)
+    with np.errstate(invalid="ignore"):
+        for c2w, depth in frames:
+            oracle.integrate(cfg.cam_K, c2w, depth, dims, origin, vs, cfg.trunc_margin, ref_t, ref_w, threads=8)
+    keep = [cuda.from_numpy(np.ascontiguousarray(d, np.float32)).cuda() for _, d in frames]
+    poses = np.stack([p for p, _ in frames])
+    for variant in (8, 0, 7):
+        with capi.Volume(cfg) as vol:
+            vol.set_kernel_variant(variant)
+            if variant == 8:
+                vol.shortcut_stats(True)
+            vol.integrate_frames_device([d.data_ptr() for d in keep], poses)
+            if variant == 8:
+                per_voxel, free, skipped = vol.shortcut_stats(False)
+                assert per_voxel + free + skipped > 0
+                if expect_claims:
+                    assert free + skipped > 0, "no workgroup-frame was claimed: the case does not exercise the classification"
+            t, w = vol.download()
+        assert np.array_equal(w, ref_w), f"variant {variant}: weights differ at {np.flatnonzero(w != ref_w)[:5]}"
+        bad = np.flatnonzero(t.view(np.uint32) != ref_t.view(np.uint32))
+        assert bad.size == 0, f"variant {variant}: {bad.size} TSDF values differ, first at {bad[:5]}"
+    return ref_t, ref_w
+
+
+@pytest.mark.parametrize("dims,vs", GRIDS)
+def test_depth_steps_on_tile_borders(cuda, oracle, dims, vs):
+    """Piecewise-constant depth whose discontinuities lie exactly on multiples of 16 pixels, at the depths where the
+    free-space claim (d >= cz_max + trunc) and the skip claim (d <= cz_min - trunc) flip, seen from poses that slide
+    the projected voxels across the tile borders in quarter-pixel steps."""
+    origin = synth.surf_volume(dims[0], vs, 0.7)
+    near, far = float(origin[2]), float(origin[2] + dims[2] * vs)
+    trunc = float(np.float32(vs) * np.float32(5))
+    rng = np.random.default_rng(3)
+    levels = np.array([far + 0.5, far + trunc, np.nextafter(np.float32(far + trunc), np.float32(0)), far + trunc * 1.01,
+                       far - 0.5 * (far - near), near + trunc, near - trunc, np.nextafter(np.float32(near - trunc), np.float32(9)),
+                       near - trunc * 1.01, near - 0.2, (near + far) / 2 + trunc, 0.0], np.float32)
+    frames = []
+    px = near / float(synth.TUM_K[0])           # metres per pixel at the near face
+    for k in range(12):
+        tiles = rng.integers(0, len(levels), (H // 16, W // 16))
+        if k % 3 == 0:
+            tiles[:] = 0                        # everything free space, with
+            tiles[rng.integers(0, H // 16, 40), rng.integers(0, W // 16, 40)] = rng.integers(1, len(levels), 40)   # islands
+        depth = np.kron(levels[tiles], np.ones((16, 16), np.float32)).astype(np.float32)
+        pose = synth.make_pose(synth.rot_z(0.01 * (k % 4)), [0.25 * k * px, -0.25 * k * px, 0.0])
+        frames.append((pose, depth))
+    run_case(cuda, oracle, dims, vs, origin, None, frames)
+
+
+@pytest.mark.parametrize("edge", ["left", "right", "top", "bottom"])
+@pytest.mark.parametrize("dims,vs", GRIDS)
+def test_patches_touching_the_image_border(cuda, oracle, dims, vs, edge):
+    """Principal point chosen so that one face of the volume projects onto an image border; the camera then slides in
+    quarter-pixel steps so projected patch boxes cross 0 / W-1 / H-1 and the +-px_margin band around them.  Constant
+    depth behind the volume (free-space claims need the box INSIDE the image) and in front of it (skip claims)."""
+    origin = synth.surf_volume(dims[0], vs, 0.7)
+    near, far = float(origin[2]), float(origin[2] + dims[2] * vs)
+    fx, fy = 535.4, 539.2
+    x0, x1 = float(origin[0]), float(origin[0]) + dims[0] * vs      # faces of the volume
+    y0, y1 = float(origin[1]), float(origin[1]) + dims[1] * vs
+    K = np.array(synth.TUM_K, np.float32)
+    if edge == "left":
+        K[2] = -fx * x0 / near                  # x = x0 at the near face lands on u = 0
+    elif edge == "right":
+        K[2] = (W - 1) - fx * x1 / near
+    elif edge == "top":
+        K[5] = -fy * y0 / near
+    else:
+        K[5] = (H - 1) - fy * y1 / near
+    px = near / fx
+    frames = []
+    for k in range(-10, 11):
+        shift = [0.25 * k * px, 0.0, 0.0] if edge in ("left", "right") else [0.0, 0.25 * k * px, 0.0]
+        depth = np.full((H, W), far + 0.5 if k % 2 == 0 else near - 0.2, np.float32)
+        frames.append((synth.make_pose(np.eye(3), shift), depth))
+    run_case(cuda, oracle, dims, vs, origin, K, frames)
+
+
+@pytest.mark.parametrize("dims,vs", GRIDS)
+def test_camera_at_the_near_plane_threshold(cuda, oracle, dims, vs):
+    """The classification trusts a projected box only when every corner has cz > cz_short (host: the bound on the slab's
+    camera-frame coordinates / 64).  The camera approaches the near face so that the first slices' corners pass through
+    that threshold in steps of a few ulp and then in coarser steps; further slices stay claimable."""
+    origin = synth.surf_volume(dims[0], vs, 0.7)
+    near, far = float(origin[2]), float(origin[2] + dims[2] * vs)
+    ext = np.array(dims, np.float64) * vs
+    frames = []
+    # the host's bound for an axis-aligned camera at distance c from the near face (tsdf_capi.hip, make_params)
+    def cz_short(c):
+        dmax = np.array([ext[0] / 2, ext[1] / 2, c + ext[2]]) * 1.001
+        return float(max(dmax) / 64.0 * 1.0001)
+    c0 = 0.0040
+    for _ in range(20):
+        c0 = cz_short(c0)                       # fixed point: a camera whose near-face cz equals its own threshold
+    cs = [np.float32(c0)]
+    for _ in range(4):
+        cs.append(np.nextafter(cs[-1], np.float32(1)))
+    lo = np.float32(c0)
+    for _ in range(4):
+        lo = np.nextafter(lo, np.float32(0))
+        cs.append(lo)
+    cs += [np.float32(c0 * f) for f in (0.5, 0.9, 0.99, 1.01, 1.1, 2.0, 8.0)]
+    for i, c in enumerate(cs):
+        depth = np.full((H, W), far - near + float(c) + (0.5 if i % 2 == 0 else -0.01), np.float32)   # behind / inside
+        frames.append((synth.make_pose(np.eye(3), [0.0, 0.0, near - float(c)]), depth))
+    run_case(cuda, oracle, dims, vs, origin, None, frames)
+
+
+@pytest.mark.parametrize("dims,vs", GRIDS)
+def test_non_finite_pixels_inside_claimable_tiles(cuda, oracle, dims, vs):
+    """A frame that is all free space (or all in front of the volume) except single NaN / +-inf / zero / negative /
+    just-beyond-max-depth pixels at tile centres, corners and borders.  NaN depth DOES update a voxel in the reference
+    (every comparison with NaN is false, ref: src/tsdf.cu:46,49), so a tile holding one may claim nothing."""
+    origin = synth.surf_volume(dims[0], vs, 0.7)
+    near, far = float(origin[2]), float(origin[2] + dims[2] * vs)
+    odd = np.array([np.nan, np.inf, -np.inf, 0.0, -1.0, np.nextafter(np.float32(6.0), np.float32(7.0)), 1e-42], np.float32)
+    rng = np.random.default_rng(5)
+    frames = []
+    for k in range(10):
+        depth = np.full((H, W), far + 0.5 if k % 2 == 0 else near - 0.2, np.float32)
+        n = 30
+        ty, tx = rng.integers(0, H // 16, n), rng.integers(0, W // 16, n)
+        oy, ox = rng.choice([0, 7, 15], n), rng.choice([0, 8, 15], n)
+        depth[ty * 16 + oy, tx * 16 + ox] = rng.choice(odd, n)
+        pose = synth.make_pose(synth.rot_y(0.01 * (k % 3)), [0.001 * k, 0.0, 0.0])
+        frames.append((pose, depth))
+    ref_t, ref_w = run_case(cuda, oracle, dims, vs, origin, None, frames)
+    assert np.isfinite(ref_t).all()

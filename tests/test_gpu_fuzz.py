@@ -35,8 +35,10 @@ def random_case(seed):
     return rng, dims, h, w, K, vs, origin, trunc, max_depth
 
 
+# 0: classification decided per launch, 7: never, 8: always -- all inside the driver's single pytest run (no env knob)
+@pytest.mark.parametrize("variant", [0, 7, 8])
 @pytest.mark.parametrize("seed", range(40))
-def test_random_configuration(cuda, oracle, seed):
+def test_random_configuration(cuda, oracle, seed, variant):
     rng, dims, h, w, K, vs, origin, trunc, max_depth = random_case(seed)
     base = synth.random_pose(rng, 0.5, 0.5) if seed % 3 else synth.identity_pose()
     cfg = capi.make_config(dims, vs, origin, trunc=trunc, K=K, base2world=base, im_height=h, im_width=w,
@@ -70,6 +72,7 @@ def test_random_configuration(cuda, oracle, seed):
         d = depth if mask is None else oracle.mask_depth(depth, mask)
         oracle.integrate(K, c2b, d, dims, origin, vs, trunc, ref_t, ref_w, max_depth=max_depth)
     with capi.Volume(cfg) as vol:
+        vol.set_kernel_variant(variant)
         keep = [(cuda.from_numpy(np.ascontiguousarray(d)).cuda(), None if m is None else cuda.from_numpy(m).cuda())
                 for _, _, d, m in frames]
         if seed % 2 == 0 and dims[0] % 4 == 0:      # as one fused sequence

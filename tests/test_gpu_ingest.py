@@ -69,30 +69,48 @@ def test_config2_1024_cube_on_the_fr3_trajectory(cuda, oracle):
     assert mid_t.min() >= -1.0 and mid_t.max() <= 1.0 and np.count_nonzero(mid_t < 1.0) > 10000
 
 
-def test_config2_full_fr3_trajectory_fused(cuda, oracle):
-    """All 194 keyframes of the reference's saved fr3_office run into a 1024^3 @ 2 mm volume through
-    tsdf_integrate_frames_device (up to 32 frames per pass over the 8.6 GB volume), every frame's depth
-    resident in HBM.  Two 3-slice slabs are replayed by the oracle frame by frame and must match bit
-    for bit; the frame count bounds every weight."""
-    Twc = ingest.pose_inverse(np.load(GOLD)["Tcw"])
-    base = Twc[0].ravel()
-    D, vs = 1024, 0.002
-    dims = (D, D, D)
-    origin = np.array([-1.024, -1.024, 0.6], np.float32)
-    cfg = capi.make_config(dims, vs, origin, base2world=base)
-    scene = synth.SurfScene(dims, vs, origin)
-    n = len(Twc)
-    c2b = [oracle.cam2base(base, Twc[k].ravel()) for k in range(n)]
-    depths = [scene.depth(c2b[k], quantize=True) for k in range(n)]
-    with capi.Volume(cfg) as vol:
-        dev = [cuda.from_numpy(d).cuda() for d in depths]
-        vol.integrate_frames_device([d.data_ptr() for d in dev], np.stack([T.ravel() for T in Twc]))
-        vol.sync()
+_TRAJ = {}
+
+
+def _trajectory(oracle):
+    """Poses, relative poses and rendered depth frames of the 194 keyframes (rendered once per session) and the oracle's
+    replay of two 3-slice slabs."""
+    if not _TRAJ:
+        Twc = ingest.pose_inverse(np.load(GOLD)["Tcw"])
+        base = Twc[0].ravel()
+        D, vs = 1024, 0.002
+        dims = (D, D, D)
+        origin = np.array([-1.024, -1.024, 0.6], np.float32)
+        cfg = capi.make_config(dims, vs, origin, base2world=base)
+        scene = synth.SurfScene(dims, vs, origin)
+        n = len(Twc)
+        c2b = [oracle.cam2base(base, Twc[k].ravel()) for k in range(n)]
+        depths = [scene.depth(c2b[k], quantize=True) for k in range(n)]
+        slabs = {}
         for zb in (300, 700):
             st, sw = oracle.init_grid(dims, zb, zb + 3)
             for k in range(n):
                 oracle.integrate(cfg.cam_K, c2b[k], depths[k], dims, origin, vs, cfg.trunc_margin, st, sw,
-                                 z_begin=zb, z_end=zb + 3)
+                                 z_begin=zb, z_end=zb + 3, threads=8)
+            slabs[zb] = (st, sw)
+        _TRAJ.update(Twc=Twc, cfg=cfg, depths=depths, slabs=slabs, n=n)
+    return _TRAJ
+
+
+@pytest.mark.parametrize("variant", [0, 7, 8])
+def test_config2_full_fr3_trajectory_fused(cuda, oracle, variant):
+    """All 194 keyframes of the reference's saved fr3_office run into a 1024^3 @ 2 mm volume through
+    tsdf_integrate_frames_device (up to 32 frames per pass over the 8.6 GB volume), every frame's depth
+    resident in HBM.  Two 3-slice slabs are replayed by the oracle frame by frame and must match bit
+    for bit; the frame count bounds every weight.  Patch classification decided per launch (0), never (7), always (8)."""
+    T = _trajectory(oracle)
+    n = T["n"]
+    with capi.Volume(T["cfg"]) as vol:
+        vol.set_kernel_variant(variant)
+        dev = [cuda.from_numpy(d).cuda() for d in T["depths"]]
+        vol.integrate_frames_device([d.data_ptr() for d in dev], np.stack([M.ravel() for M in T["Twc"]]))
+        vol.sync()
+        for zb, (st, sw) in T["slabs"].items():
             gt, gw = vol.copy_slices(zb, 3)
             assert sw.max() > 20, "the trajectory should see these slices many times"
             assert np.array_equal(gw, sw) and np.array_equal(gt.view(np.uint32), st.view(np.uint32))

@@ -319,31 +319,72 @@ def test_surface_and_files_match_oracle(cuda, oracle, tmp_path):
     assert (tmp_path / "a.bin").read_bytes() == (tmp_path / "b.bin").read_bytes()
 
 
-def test_full_size_512_sfull(cuda, oracle):
-    """BASELINE config[1]: 512^3 @ 5 mm, full-coverage input.  Checked against the oracle on a
-    z-slab sample and through size-independent properties on the whole grid."""
+@pytest.mark.parametrize("path", ["frame", "fused", "fused_classified", "fused_per_voxel"])
+def test_full_size_512_sfull(cuda, oracle, path):
+    """BASELINE config[1]: 512^3 @ 5 mm, full-coverage input, through the one-launch-per-frame kernel and through the
+    fused sequence path (default, classification forced on, forced off).  Checked against the oracle on three
+    z-slabs and through size-independent properties on the whole grid."""
     D, vs = 512, 0.005
     origin = synth.sfull_volume(D, vs)
     cfg = capi.make_config((D, D, D), vs, origin)
     depth = synth.sfull_depth()
-    frames = 3
+    frames = 3 if path == "frame" else 35          # 35: one full 32-frame pass + a 3-frame one
+    poses = np.stack([synth.sfull_pose(k) for k in range(frames)])
     with capi.Volume(cfg) as vol:
         d_dev = dev(cuda, depth)
-        for k in range(frames):
-            vol.integrate_device(d_dev.data_ptr(), synth.sfull_pose(k))
+        if path == "frame":
+            for k in range(frames):
+                vol.integrate_device(d_dev.data_ptr(), poses[k])
+        else:
+            vol.set_kernel_variant({"fused": 0, "fused_classified": 8, "fused_per_voxel": 7}[path])
+            vol.integrate_frames_device([d_dev.data_ptr()] * frames, poses)
         t, w = vol.download()
     # property: every voxel updated every frame, and the mean of dist = 1 stays exactly 1
     assert np.all(w == float(frames)), "S-full must update every voxel every frame (N_upd == N)"
     assert np.all(t == 1.0)
-    # oracle on three slabs (first, middle, last 8 slices)
-    for zb in (0, 252, 504):
-        st, sw = oracle.init_grid((D, D, D), zb, zb + 8)
+    # oracle on three slabs (first, middle, last 4 slices)
+    for zb in (0, 254, 508):
+        st, sw = oracle.init_grid((D, D, D), zb, zb + 4)
         n = 0
         for k in range(frames):
-            n += oracle.integrate(cfg.cam_K, synth.sfull_pose(k), depth, (D, D, D), origin, vs,
-                                  cfg.trunc_margin, st, sw, z_begin=zb, z_end=zb + 8)
-        assert n == frames * 8 * D * D
-        lo, hi = zb * D * D, (zb + 8) * D * D
+            n += oracle.integrate(cfg.cam_K, poses[k], depth, (D, D, D), origin, vs,
+                                  cfg.trunc_margin, st, sw, z_begin=zb, z_end=zb + 4)
+        assert n == frames * 4 * D * D
+        lo, hi = zb * D * D, (zb + 4) * D * D
+        assert_parity(t[lo:hi], w[lo:hi], st, sw)
+
+
+@pytest.mark.parametrize("path", ["frame", "fused", "fused_classified"])
+def test_full_size_512_sband(cuda, oracle, path):
+    """The bench headline's workload at full size: 512^3 @ 5 mm S-band -- every voxel updated by every frame INSIDE the
+    truncation band (4 m margin), so dist < 1, both divisions run and every TSDF value changes every frame; nothing can
+    be elided or claimed.  Per-frame launches and the fused sequence path against the oracle on four z-slabs, bit for
+    bit, plus whole-grid properties."""
+    D, vs = 512, 0.005
+    origin = synth.sband_volume(D, vs)
+    cfg = capi.make_config((D, D, D), vs, origin, trunc=synth.SBAND_TRUNC)
+    depth = synth.sfull_depth()
+    frames = 5 if path == "frame" else 37
+    poses = np.stack([synth.sband_pose(k) for k in range(frames)])
+    with capi.Volume(cfg) as vol:
+        d_dev = dev(cuda, depth)
+        if path == "frame":
+            for k in range(frames):
+                vol.integrate_device(d_dev.data_ptr(), poses[k])
+        else:
+            vol.set_kernel_variant(0 if path == "fused" else 8)
+            vol.integrate_frames_device([d_dev.data_ptr()] * frames, poses)
+        t, w = vol.download()
+    assert np.all(w == float(frames)), "S-band must update every voxel every frame (N_upd == N)"
+    assert 0.0 < t.min() and t.max() < 1.0, "every voxel inside the truncation band"
+    for zb in (0, 171, 340, 509):
+        st, sw = oracle.init_grid((D, D, D), zb, zb + 3)
+        n = 0
+        for k in range(frames):
+            n += oracle.integrate(cfg.cam_K, poses[k], depth, (D, D, D), origin, vs,
+                                  cfg.trunc_margin, st, sw, z_begin=zb, z_end=zb + 3, threads=8)
+        assert n == frames * 3 * D * D
+        lo, hi = zb * D * D, (zb + 3) * D * D
         assert_parity(t[lo:hi], w[lo:hi], st, sw)
 
 
