@@ -12,6 +12,8 @@
 //
 // Additions the reference lacks (all optional; defaults reproduce the reference):
 //     TSDF(const tsdf_config&)   run-time grid size / voxel size / intrinsics / z-slab / device
+//     TSDF(const tsdf_config&, devices)   the same grid cut into z-slabs over several GPUs of the node, in this
+//                                process (tsdf_group_*): Integrate fans the frame out, the destructor gathers
 //     Download(), Sync()         read results back without destroying the object
 //     SetSaveOnDestroy(false)    skip the two files the destructor writes
 //     TSDF::ThrowOnError(true)   throw std::runtime_error instead of print + exit(1)
@@ -40,6 +42,11 @@ class TSDF
 	/** Run-time configured volume (not in the reference). */
 	explicit TSDF(const tsdf_config &cfg);
 
+	/** The grid of cfg cut into devices.size() contiguous z-slabs, slab i on HIP device devices[i] (not in the
+	reference, which is single-GPU).  Same Integrate / Download / destructor behaviour; results and files are
+	bit-identical to the single-device object. */
+	TSDF(const tsdf_config &cfg, const std::vector<int> &devices);
+
 	/** Downloads the grid, writes tsdf<id>.ply and tsdf<id>.bin (ref: src/tsdf.cu:98-133). */
 	~TSDF();
 
@@ -59,7 +66,8 @@ class TSDF
 	void Download();                        ///< refresh the two host mirrors now
 	void Sync();                            ///< wait for queued integrations
 	void SetSaveOnDestroy(bool on) { save_on_destroy_ = on; }
-	tsdf_volume *handle() const { return vol_; }
+	tsdf_volume *handle() const { return vol_; }   ///< NULL for a multi-device object
+	tsdf_group *group() const { return grp_; }     ///< NULL for a single-device object
 	const tsdf_config &config() const { return cfg_; }
 	static void ThrowOnError(bool on);      ///< default false: print to stderr and exit(EXIT_FAILURE)
 
@@ -69,8 +77,11 @@ class TSDF
 	TSDF &operator=(const TSDF &);
 	void init();
 	void fail(const char *what, int line) const;
+	long long voxels() const;
 	tsdf_config cfg_;
 	tsdf_volume *vol_;
+	tsdf_group *grp_;
+	std::vector<int> devices_;
 	bool save_on_destroy_;
 };
 #endif // TSDF_HIP_DROPIN_TSDF_HPP

@@ -358,6 +358,49 @@ int tsdf_batch_integrate_device(tsdf_batch *batch, const float *depth_dev, const
                                 const float cam2world[16]);
 int tsdf_batch_sync(tsdf_batch *batch);
 
+/*
+ * One grid over several devices in ONE process.  The reference's host is a C++ program that owns its TSDFs directly
+ * (ref: include/tsdf.hpp:22-43; src/Engine.cpp:170-172 drives distinct TSDFs from one loop), so a C++ caller must be
+ * able to span the node without a process per GPU.  tsdf_group_create cuts the grid of *cfg (its z_begin / z_end /
+ * device fields are ignored) into n_slabs contiguous z-slabs -- slab i holds z in [i*dim_z/n, (i+1)*dim_z/n) and lives
+ * on devices[i], with its own stream; ordinals may repeat (several slabs on one device).  Needs n_slabs <= dim_z.
+ *   tsdf_group_integrate         TSDF::Integrate for the whole grid (ref: src/tsdf.cu:135-168): the caller's frame is
+ *                                copied once into pinned memory, fanned out with one asynchronous copy per slab on that
+ *                                slab's stream and followed by its kernel; no synchronisation between devices and no
+ *                                collective (voxels are independent); returns without waiting
+ *   tsdf_group_integrate_frames  a known sequence from host frames: per pass of up to 32 frames, one copy of the
+ *                                frames to every device and one fused launch per slab (tsdf_integrate_frames_device)
+ *   tsdf_group_download          the whole grid in z order (== one handle's tsdf_download, bit for bit)
+ *   tsdf_group_extract_*         lists of the whole grid in grid order; zero crossings and the mesh fetch slice z_end
+ *                                from the next slab device to device (hipMemcpyPeerAsync, dim_y*dim_x*8 bytes per
+ *                                boundary); one host thread per slab, so the devices extract concurrently
+ *   tsdf_group_save_*            the reference's files (ref: src/tsdf.cu:107-132,170-218), byte-identical to a
+ *                                whole-grid handle's
+ *   tsdf_group_volume            borrow slab i's handle (tsdf_device_ptrs, tsdf_set_kernel_variant, ...); it is
+ *                                destroyed with the group
+ */
+typedef struct tsdf_group tsdf_group;
+int tsdf_group_create(const tsdf_config *cfg, const int32_t *devices, int32_t n_slabs, tsdf_group **out);
+int tsdf_group_destroy(tsdf_group *group);
+int tsdf_group_size(const tsdf_group *group);
+int64_t tsdf_group_voxels(const tsdf_group *group);
+int tsdf_group_volume(tsdf_group *group, int32_t i, tsdf_volume **vol);
+int tsdf_group_integrate(tsdf_group *group, const float *depth_host, const float cam2world[16]);
+int tsdf_group_integrate_frames(tsdf_group *group, const float *const *depth_host, const float *cam2world,
+                                int32_t n_frames);
+int tsdf_group_sync(tsdf_group *group);
+int tsdf_group_reset(tsdf_group *group);
+int tsdf_group_download(tsdf_group *group, float *tsdf_host, float *weight_host);
+int tsdf_group_extract_surface(tsdf_group *group, float weight_thresh, float *xyz_host, int64_t capacity,
+                               int64_t *count);
+int tsdf_group_extract_crossings(tsdf_group *group, float weight_thresh, float *xyz_host, int64_t capacity,
+                                 int64_t *count);
+int tsdf_group_extract_mesh(tsdf_group *group, float weight_thresh, float *triangles_host, int64_t capacity,
+                            int64_t *count);
+int tsdf_group_save_ply(tsdf_group *group, const char *path, float weight_thresh);
+int tsdf_group_save_mesh_ply(tsdf_group *group, const char *path, float weight_thresh);
+int tsdf_group_save_bin(tsdf_group *group, const char *path);
+
 /* Message describing the last failure on this thread ("" when none). */
 const char *tsdf_last_error(void);
 

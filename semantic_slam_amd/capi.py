@@ -28,6 +28,10 @@ ABI_SYMBOLS = [
     "tsdf_download_labels",
     "tsdf_object_origin", "tsdf_batch_create", "tsdf_batch_destroy", "tsdf_batch_size", "tsdf_batch_volume",
     "tsdf_batch_integrate_device", "tsdf_batch_sync",
+    "tsdf_group_create", "tsdf_group_destroy", "tsdf_group_size", "tsdf_group_voxels", "tsdf_group_volume",
+    "tsdf_group_integrate", "tsdf_group_integrate_frames", "tsdf_group_sync", "tsdf_group_reset", "tsdf_group_download",
+    "tsdf_group_extract_surface", "tsdf_group_extract_crossings", "tsdf_group_extract_mesh",
+    "tsdf_group_save_ply", "tsdf_group_save_mesh_ply", "tsdf_group_save_bin",
 ]
 
 
@@ -120,6 +124,22 @@ def load():
     L.tsdf_batch_volume.argtypes = [vp, C.c_int32, C.POINTER(vp)]
     L.tsdf_batch_integrate_device.argtypes = [vp, vp, vp, vp]
     L.tsdf_batch_sync.argtypes = [vp]
+    L.tsdf_group_create.argtypes = [C.POINTER(TsdfConfig), C.POINTER(C.c_int32), C.c_int32, C.POINTER(vp)]
+    L.tsdf_group_destroy.argtypes = [vp]
+    L.tsdf_group_size.argtypes = [vp]
+    L.tsdf_group_voxels.argtypes = [vp]
+    L.tsdf_group_voxels.restype = C.c_int64
+    L.tsdf_group_volume.argtypes = [vp, C.c_int32, C.POINTER(vp)]
+    L.tsdf_group_integrate.argtypes = [vp, vp, vp]
+    L.tsdf_group_integrate_frames.argtypes = [vp, vp, vp, C.c_int32]
+    L.tsdf_group_sync.argtypes = [vp]
+    L.tsdf_group_reset.argtypes = [vp]
+    L.tsdf_group_download.argtypes = [vp, vp, vp]
+    for name in ("tsdf_group_extract_surface", "tsdf_group_extract_crossings", "tsdf_group_extract_mesh"):
+        getattr(L, name).argtypes = [vp, C.c_float, vp, C.c_int64, i64p]
+    L.tsdf_group_save_ply.argtypes = [vp, C.c_char_p, C.c_float]
+    L.tsdf_group_save_mesh_ply.argtypes = [vp, C.c_char_p, C.c_float]
+    L.tsdf_group_save_bin.argtypes = [vp, C.c_char_p]
     _lib = L
     return L
 
@@ -515,6 +535,95 @@ class Batch:
             for v in self.volumes:
                 v.close()
             self.lib.tsdf_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+class Group:
+    """One grid cut into z-slabs over several devices in one process (tsdf_group_*)."""
+
+    def __init__(self, cfg, devices):
+        self.lib = load()
+        self.cfg = cfg
+        self.devices = [int(d) for d in devices]
+        arr = (C.c_int32 * len(self.devices))(*self.devices)
+        self._h = C.c_void_p()
+        check(self.lib.tsdf_group_create(C.byref(cfg), arr, len(self.devices), C.byref(self._h)), "tsdf_group_create")
+        self.slabs = []
+        for i in range(len(self.devices)):
+            h = C.c_void_p()
+            check(self.lib.tsdf_group_volume(self._h, i, C.byref(h)), "tsdf_group_volume")
+            c = TsdfConfig()
+            check(self.lib.tsdf_get_config(h, C.byref(c)), "tsdf_get_config")
+            self.slabs.append(Volume(c, _borrowed_handle=h))
+
+    @property
+    def n_voxels(self):
+        return int(self.lib.tsdf_group_voxels(self._h))
+
+    def integrate(self, depth_host, cam2world):
+        d = _f32(depth_host, self.cfg.im_height * self.cfg.im_width)
+        p = _f32(cam2world, 16)
+        check(self.lib.tsdf_group_integrate(self._h, d.ctypes.data, p.ctypes.data), "tsdf_group_integrate")
+
+    def integrate_frames(self, depths_host, poses):
+        keep = [_f32(d, self.cfg.im_height * self.cfg.im_width) for d in depths_host]
+        p = _f32(np.asarray(poses, dtype=np.float32))
+        n = p.size // 16
+        assert len(keep) == n
+        ptrs = (C.c_void_p * n)(*[C.c_void_p(d.ctypes.data) for d in keep])
+        check(self.lib.tsdf_group_integrate_frames(self._h, ptrs, p.ctypes.data, n), "tsdf_group_integrate_frames")
+
+    def sync(self):
+        check(self.lib.tsdf_group_sync(self._h), "tsdf_group_sync")
+
+    def reset(self):
+        check(self.lib.tsdf_group_reset(self._h), "tsdf_group_reset")
+
+    def download(self):
+        n = self.n_voxels
+        t, w = np.empty(n, np.float32), np.empty(n, np.float32)
+        check(self.lib.tsdf_group_download(self._h, t.ctypes.data, w.ctypes.data), "tsdf_group_download")
+        return t, w
+
+    def _list(self, fn, shape, weight_thresh):
+        n = C.c_int64()
+        check(fn(self._h, weight_thresh, None, 0, C.byref(n)), "tsdf_group_extract")
+        out = np.empty((n.value,) + shape, np.float32)
+        if n.value:
+            got = C.c_int64()
+            check(fn(self._h, weight_thresh, out.ctypes.data, n.value, C.byref(got)), "tsdf_group_extract")
+            assert got.value == n.value
+        return out
+
+    def extract_surface(self, weight_thresh=0.9):
+        return self._list(self.lib.tsdf_group_extract_surface, (3,), weight_thresh)
+
+    def extract_crossings(self, weight_thresh=0.9):
+        return self._list(self.lib.tsdf_group_extract_crossings, (3,), weight_thresh)
+
+    def extract_mesh(self, weight_thresh=0.9):
+        return self._list(self.lib.tsdf_group_extract_mesh, (3, 3), weight_thresh)
+
+    def save_ply(self, path, weight_thresh=0.9):
+        check(self.lib.tsdf_group_save_ply(self._h, os.fsencode(path), weight_thresh), "tsdf_group_save_ply")
+
+    def save_mesh_ply(self, path, weight_thresh=0.9):
+        check(self.lib.tsdf_group_save_mesh_ply(self._h, os.fsencode(path), weight_thresh), "tsdf_group_save_mesh_ply")
+
+    def save_bin(self, path):
+        check(self.lib.tsdf_group_save_bin(self._h, os.fsencode(path)), "tsdf_group_save_bin")
+
+    def close(self):
+        if self._h:
+            for v in self.slabs:
+                v.close()
+            self.lib.tsdf_group_destroy(self._h)
             self._h = C.c_void_p()
 
     def __enter__(self):

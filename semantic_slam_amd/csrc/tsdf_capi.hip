@@ -595,6 +595,55 @@ int ensure_scratch(tsdf_volume *v, size_t bytes)
     return TSDF_OK;
 }
 
+// ---- file writers shared by the single-handle and the group entry points ---------------------------------------
+// .ply of surface points: header text of ref: src/tsdf.cu:185-192 (the vertex count is printed with %d there)
+int write_points_ply(const char *path, const float *xyz, int64_t n, const char *who)
+{
+    FILE *fp = std::fopen(path, "w");
+    if (!fp) return fail(TSDF_ERR_IO, "%s: cannot open %s", who, path);
+    std::fprintf(fp, "ply\nformat binary_little_endian 1.0\nelement vertex %d\n", (int)n);
+    std::fprintf(fp, "property float x\nproperty float y\nproperty float z\nend_header\n");
+    size_t wrote = std::fwrite(xyz, sizeof(float), (size_t)n * 3, fp);
+    int bad = std::fclose(fp);
+    if (wrote != (size_t)n * 3 || bad) return fail(TSDF_ERR_IO, "%s: short write to %s", who, path);
+    return TSDF_OK;
+}
+
+// binary .ply with vertex + face elements, three vertices per triangle
+int write_mesh_ply(const char *path, const float *tri, int64_t n, const char *who)
+{
+    FILE *fp = std::fopen(path, "wb");
+    if (!fp) return fail(TSDF_ERR_IO, "%s: cannot open %s", who, path);
+    std::fprintf(fp, "ply\nformat binary_little_endian 1.0\nelement vertex %lld\n", (long long)(3 * n));
+    std::fprintf(fp, "property float x\nproperty float y\nproperty float z\n");
+    std::fprintf(fp, "element face %lld\nproperty list uchar int vertex_indices\nend_header\n", (long long)n);
+    size_t ok = std::fwrite(tri, sizeof(float), (size_t)n * 9, fp);
+    std::vector<unsigned char> faces((size_t)(n > 0 ? n : 1) * 13);
+    for (int64_t f = 0; f < n; ++f) {
+        unsigned char *rec = faces.data() + 13 * f;
+        rec[0] = 3;
+        for (int k = 0; k < 3; ++k) { const int32_t idx = (int32_t)(3 * f + k); std::memcpy(rec + 1 + 4 * k, &idx, 4); }
+    }
+    ok += std::fwrite(faces.data(), 13, (size_t)n, fp);
+    int bad = std::fclose(fp);
+    if (ok != (size_t)n * 9 + (size_t)n || bad) return fail(TSDF_ERR_IO, "%s: short write to %s", who, path);
+    return TSDF_OK;
+}
+
+// ref: src/tsdf.cu:119-129 -- dims as floats, origin, voxel size, truncation margin, then the TSDF values
+int write_bin(const char *path, int dx, int dy, int dz, const float origin[3], float vs, float trunc, const float *data,
+              int64_t n, const char *who)
+{
+    FILE *fp = std::fopen(path, "wb");
+    if (!fp) return fail(TSDF_ERR_IO, "%s: cannot open %s", who, path);
+    float hdr[8] = {(float)dx, (float)dy, (float)dz, origin[0], origin[1], origin[2], vs, trunc};
+    size_t ok = std::fwrite(hdr, sizeof(float), 8, fp);
+    ok += std::fwrite(data, sizeof(float), (size_t)n, fp);  // one write, not one per float
+    int bad = std::fclose(fp);
+    if (ok != 8 + (size_t)n || bad) return fail(TSDF_ERR_IO, "%s: short write to %s", who, path);
+    return TSDF_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1514,22 +1563,7 @@ int tsdf_save_mesh_ply(tsdf_volume *v, const char *path, float weight_thresh)
         rc = crossing_pass(v, nullptr, nullptr, weight_thresh, tri.data(), n, &n, true);
         if (rc) return rc;
     }
-    FILE *fp = std::fopen(path, "wb");
-    if (!fp) return fail(TSDF_ERR_IO, "tsdf_save_mesh_ply: cannot open %s", path);
-    std::fprintf(fp, "ply\nformat binary_little_endian 1.0\nelement vertex %lld\n", (long long)(3 * n));
-    std::fprintf(fp, "property float x\nproperty float y\nproperty float z\n");
-    std::fprintf(fp, "element face %lld\nproperty list uchar int vertex_indices\nend_header\n", (long long)n);
-    size_t ok = std::fwrite(tri.data(), sizeof(float), (size_t)n * 9, fp);
-    std::vector<unsigned char> faces((size_t)(n > 0 ? n : 1) * 13);
-    for (int64_t f = 0; f < n; ++f) {
-        unsigned char *rec = faces.data() + 13 * f;
-        rec[0] = 3;
-        for (int k = 0; k < 3; ++k) { const int32_t idx = (int32_t)(3 * f + k); std::memcpy(rec + 1 + 4 * k, &idx, 4); }
-    }
-    ok += std::fwrite(faces.data(), 13, (size_t)n, fp);
-    int bad = std::fclose(fp);
-    if (ok != (size_t)n * 9 + (size_t)n || bad) return fail(TSDF_ERR_IO, "tsdf_save_mesh_ply: short write to %s", path);
-    return TSDF_OK;
+    return write_mesh_ply(path, tri.data(), n, "tsdf_save_mesh_ply");
 }
 
 int tsdf_save_ply(tsdf_volume *v, const char *path, float weight_thresh)
@@ -1545,15 +1579,7 @@ int tsdf_save_ply(tsdf_volume *v, const char *path, float weight_thresh)
         rc = surface_pass(v, weight_thresh, xyz.data(), n, &n);
         if (rc) return rc;
     }
-    FILE *fp = std::fopen(path, "w");
-    if (!fp) return fail(TSDF_ERR_IO, "tsdf_save_ply: cannot open %s", path);
-    // header text of ref: src/tsdf.cu:185-192 (the vertex count is printed with %d there)
-    std::fprintf(fp, "ply\nformat binary_little_endian 1.0\nelement vertex %d\n", (int)n);
-    std::fprintf(fp, "property float x\nproperty float y\nproperty float z\nend_header\n");
-    size_t wrote = std::fwrite(xyz.data(), sizeof(float), (size_t)n * 3, fp);
-    int bad = std::fclose(fp);
-    if (wrote != (size_t)n * 3 || bad) return fail(TSDF_ERR_IO, "tsdf_save_ply: short write to %s", path);
-    return TSDF_OK;
+    return write_points_ply(path, xyz.data(), n, "tsdf_save_ply");
 }
 
 int tsdf_save_bin(tsdf_volume *v, const char *path)
@@ -1562,17 +1588,9 @@ int tsdf_save_bin(tsdf_volume *v, const char *path)
     std::vector<float> host((size_t)(v->n_vox > 0 ? v->n_vox : 1));
     int rc = tsdf_download(v, host.data(), nullptr);
     if (rc) return rc;
-    FILE *fp = std::fopen(path, "wb");
-    if (!fp) return fail(TSDF_ERR_IO, "tsdf_save_bin: cannot open %s", path);
     const tsdf_config &c = v->cfg;
-    // ref: src/tsdf.cu:119-129 -- dims as floats, origin, voxel size, truncation margin
-    float hdr[8] = {(float)c.dim_x, (float)c.dim_y, (float)(c.z_end - c.z_begin),
-                    c.origin[0], c.origin[1], c.origin[2], c.voxel_size, c.trunc_margin};
-    size_t ok = std::fwrite(hdr, sizeof(float), 8, fp);
-    ok += std::fwrite(host.data(), sizeof(float), (size_t)v->n_vox, fp);  // one write, not one per float
-    int bad = std::fclose(fp);
-    if (ok != 8 + (size_t)v->n_vox || bad) return fail(TSDF_ERR_IO, "tsdf_save_bin: short write to %s", path);
-    return TSDF_OK;
+    return write_bin(path, c.dim_x, c.dim_y, c.z_end - c.z_begin, c.origin, c.voxel_size, c.trunc_margin, host.data(), v->n_vox,
+                     "tsdf_save_bin");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1634,3 +1652,5 @@ int tsdf_load_state(tsdf_volume *v, const char *path)
 }
 
 }  // extern "C"
+
+#include "tsdf_group.hip.h"

@@ -28,7 +28,7 @@ void TSDF::fail(const char *what, int line) const
 }
 
 TSDF::TSDF(int h, int w, int MOid, std::vector<float> base2world_, std::vector<float> origin)
-	: voxel_grid_TSDF(NULL), voxel_grid_weight(NULL), vol_(NULL), save_on_destroy_(true)
+	: voxel_grid_TSDF(NULL), voxel_grid_weight(NULL), vol_(NULL), grp_(NULL), save_on_destroy_(true)
 {
 	tsdf_config_default(&cfg_, h, w);  // 200^3 @ 4 mm, trunc 20 mm, TUM K (ref: include/tsdf.hpp:63-67,96)
 	cfg_.id = MOid;
@@ -38,15 +38,31 @@ TSDF::TSDF(int h, int w, int MOid, std::vector<float> base2world_, std::vector<f
 }
 
 TSDF::TSDF(const tsdf_config &cfg)
-	: voxel_grid_TSDF(NULL), voxel_grid_weight(NULL), cfg_(cfg), vol_(NULL), save_on_destroy_(true)
+	: voxel_grid_TSDF(NULL), voxel_grid_weight(NULL), cfg_(cfg), vol_(NULL), grp_(NULL), save_on_destroy_(true)
 {
 	init();
 }
 
+TSDF::TSDF(const tsdf_config &cfg, const std::vector<int> &devices)
+	: voxel_grid_TSDF(NULL), voxel_grid_weight(NULL), cfg_(cfg), vol_(NULL), grp_(NULL), devices_(devices),
+	  save_on_destroy_(true)
+{
+	cfg_.z_begin = 0;
+	cfg_.z_end = cfg_.dim_z;
+	init();
+}
+
+long long TSDF::voxels() const { return grp_ ? tsdf_group_voxels(grp_) : tsdf_slab_voxels(vol_); }
+
 void TSDF::init()
 {
-	if (tsdf_create(&cfg_, &vol_) != TSDF_OK) fail("tsdf_create", __LINE__);
-	const long long n = tsdf_slab_voxels(vol_);
+	if (!devices_.empty()) {
+		std::vector<int32_t> dev(devices_.begin(), devices_.end());
+		if (tsdf_group_create(&cfg_, dev.data(), (int32_t)dev.size(), &grp_) != TSDF_OK) fail("tsdf_group_create", __LINE__);
+	} else if (tsdf_create(&cfg_, &vol_) != TSDF_OK) {
+		fail("tsdf_create", __LINE__);
+	}
+	const long long n = voxels();
 	if (n <= kEagerMirrorLimit) {
 		// ref: src/tsdf.cu:77-81 -- host mirrors exist from construction, TSDF = 1, weight = 0
 		voxel_grid_TSDF = new float[n > 0 ? n : 1];
@@ -60,35 +76,42 @@ void TSDF::Integrate(float *depth_im, std::vector<float> cam2world_vec)
 {
 	float cam2world[16] = {0};
 	for (size_t i = 0; i < 16 && i < cam2world_vec.size(); ++i) cam2world[i] = cam2world_vec[i];  // ref: src/tsdf.cu:139
-	if (tsdf_integrate(vol_, depth_im, cam2world) != TSDF_OK) fail("tsdf_integrate", __LINE__);
+	const int rc = grp_ ? tsdf_group_integrate(grp_, depth_im, cam2world) : tsdf_integrate(vol_, depth_im, cam2world);
+	if (rc != TSDF_OK) fail("tsdf_integrate", __LINE__);
 }
 
 void TSDF::Sync()
 {
-	if (tsdf_sync(vol_) != TSDF_OK) fail("tsdf_sync", __LINE__);
+	if ((grp_ ? tsdf_group_sync(grp_) : tsdf_sync(vol_)) != TSDF_OK) fail("tsdf_sync", __LINE__);
 }
 
 void TSDF::Download()
 {
-	const long long n = tsdf_slab_voxels(vol_);
+	const long long n = voxels();
 	if (!voxel_grid_TSDF) voxel_grid_TSDF = new float[n > 0 ? n : 1];
 	if (!voxel_grid_weight) voxel_grid_weight = new float[n > 0 ? n : 1];
-	if (tsdf_download(vol_, voxel_grid_TSDF, voxel_grid_weight) != TSDF_OK) fail("tsdf_download", __LINE__);
+	const int rc = grp_ ? tsdf_group_download(grp_, voxel_grid_TSDF, voxel_grid_weight)
+	                    : tsdf_download(vol_, voxel_grid_TSDF, voxel_grid_weight);
+	if (rc != TSDF_OK) fail("tsdf_download", __LINE__);
 }
 
 TSDF::~TSDF()
 {
-	if (vol_) {
+	if (vol_ || grp_) {
 		if (save_on_destroy_) {
 			Download();  // ref: src/tsdf.cu:101-104
 			// ref: src/tsdf.cu:109-112 -- surface points, weight threshold 0.9 (tsdf_thresh 1.2 is unused there)
 			std::string name = "tsdf" + std::to_string(cfg_.id) + ".ply";
-			if (tsdf_save_ply(vol_, name.c_str(), 0.9f) != TSDF_OK) fail("tsdf_save_ply", __LINE__);
+			if ((grp_ ? tsdf_group_save_ply(grp_, name.c_str(), 0.9f) : tsdf_save_ply(vol_, name.c_str(), 0.9f)) != TSDF_OK)
+				fail("tsdf_save_ply", __LINE__);
 			name = "tsdf" + std::to_string(cfg_.id) + ".bin";  // ref: src/tsdf.cu:116-132
-			if (tsdf_save_bin(vol_, name.c_str()) != TSDF_OK) fail("tsdf_save_bin", __LINE__);
+			if ((grp_ ? tsdf_group_save_bin(grp_, name.c_str()) : tsdf_save_bin(vol_, name.c_str())) != TSDF_OK)
+				fail("tsdf_save_bin", __LINE__);
 		}
-		tsdf_destroy(vol_);
+		if (grp_) tsdf_group_destroy(grp_);
+		if (vol_) tsdf_destroy(vol_);
 		vol_ = NULL;
+		grp_ = NULL;
 	}
 	delete[] voxel_grid_TSDF;    // the reference leaks both mirrors and the device buffers
 	delete[] voxel_grid_weight;

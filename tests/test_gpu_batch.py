@@ -88,8 +88,8 @@ def test_object_origin_negative_zero_and_stream_order(cuda, oracle):
     atomic must take its branch by the sign BIT (pattern 0x80000000 is INT_MIN as a signed integer).  Also: the
     frame is produced on a handle's own (non-blocking) stream right before the call -- no tsdf_sync in between."""
     depth = np.zeros((480, 640), np.float32)
-    depth[100:300, 400:600] = 1.5                      # right of cx, below... both x > 0 and mixed y
-    depth[200, 10] = 1e-45                             # denormal: (10 - 320.1) * 1e-45 underflows to -0.0
+    depth[100:300, 400:600] = 1.5                      # right of the principal point: every other x is > 0
+    depth[200, 320] = 1e-45                            # denormal: (320 - 320.1) * 1.4e-45 underflows to -0.0
     want = oracle.object_origin(depth, synth.TUM_K)
     assert want.view(np.uint32)[0] == 0x80000000, "the case must produce x = -0.0 in the reference's loop"
     raw = np.zeros((480, 640), np.uint16)
