@@ -101,6 +101,9 @@ struct tsdf_volume {
     // scratch for surface extraction (allocated on first use)
     void *d_scratch;
     size_t scratch_bytes;
+    // class of every workgroup of a one-frame masked launch (classify_workgroups), grown on demand
+    uint8_t *d_wg_class;
+    size_t wg_class_bytes;
     // output list of the extraction passes (points / vertices / triangles), grown on demand and kept
     void *d_list;
     size_t list_bytes;
@@ -121,6 +124,10 @@ struct tsdf_batch {
     int slot_next;
     int2 *d_slice_map;
     int total_slices, max_blocks;
+    // per-object depth tile tables of the current frame and the class of every workgroup of the launch
+    float2 *d_tiles;
+    size_t tiles_per_object;
+    uint8_t *d_wg_class;
 };
 
 namespace {
@@ -209,7 +216,82 @@ tsdfk::IntegrateParams make_params(const tsdf_volume *v, const float *depth_dev,
     p.px_margin_v = (float)(1.5 + 3.2e-5 * (std::fabs((double)p.fy) + 4.0 * (c.im_height + std::fabs((double)p.cy))));
     p.shortcut_stats = v->d_shortcut_stats;
     p.claim_counter = nullptr;
+    p.wg_class = nullptr;
     return p;
+}
+
+// The per-frame block of the fused / flat kernels from a full parameter set.
+void pose_from_params(tsdfk::FramePose &fp, const tsdfk::IntegrateParams &q)
+{
+    fp.depth = q.depth; fp.mask = q.mask;
+    fp.rx0 = q.rx0; fp.rx1 = q.rx1; fp.rx2 = q.rx2;
+    fp.ry0 = q.ry0; fp.ry1 = q.ry1; fp.ry2 = q.ry2;
+    fp.rz0 = q.rz0; fp.rz1 = q.rz1; fp.rz2 = q.rz2;
+    fp.tx = q.tx; fp.ty = q.ty; fp.tz = q.tz;
+    fp.fast_ok = q.fast_ok; fp.cz_margin = q.cz_margin;
+    fp.label_im = nullptr; fp.score_im = nullptr;
+    fp.tiles = nullptr;
+    fp.cz_short = q.cz_short; fp.cz_pad = q.cz_pad;
+}
+
+int tile_levels_host(int n) { int l = 0; while (n > 0) { ++l; n >>= 1; } return l; }
+
+size_t tile_table_elems_host(int tiles_w, int tiles_h)
+{
+    return (size_t)tile_levels_host(tiles_w) * tile_levels_host(tiles_h) * tiles_w * tiles_h;
+}
+
+bool tiles_fit(const tsdfk::IntegrateParams &p) { return (int64_t)p.tiles_w * p.tiles_h <= 8192; }
+
+// Depth tile tables (summary + sparse table, tsdf_multiframe.hip.h) of n images depth[i] x mask[i] into tables[i], queued
+// on `stream`; two small launches per 32 images.
+int build_tile_tables(hipStream_t stream, const tsdf_config &c, const tsdfk::IntegrateParams &p, const float *const *depth,
+                      const uint8_t *const *masks, int n, float2 *tables)
+{
+    const size_t per = tile_table_elems_host(p.tiles_w, p.tiles_h);
+    for (int k = 0; k < n; k += tsdfk::kMaxFramesPerLaunch) {
+        const int m = std::min(tsdfk::kMaxFramesPerLaunch, n - k);
+        tsdfk::TileSummaryParams tp;
+        for (int f = 0; f < tsdfk::kMaxFramesPerLaunch; ++f) {
+            tp.depth[f] = depth[k + (f < m ? f : 0)];
+            tp.mask[f] = masks ? masks[k + (f < m ? f : 0)] : nullptr;
+        }
+        tp.tiles = tables + (size_t)k * per;
+        tp.H = c.im_height; tp.W = c.im_width; tp.tiles_w = p.tiles_w; tp.tiles_h = p.tiles_h;
+        tp.max_depth = c.max_depth;
+        hipLaunchKernelGGL(tsdfk::depth_tile_summary, dim3((unsigned)(p.tiles_w * p.tiles_h), m), dim3(64), 0, stream, tp);
+        hipLaunchKernelGGL(tsdfk::tile_sparse_table, dim3(m), dim3(256), 0, stream, tp.tiles, p.tiles_w, p.tiles_h);
+    }
+    HIP_TRY(hipGetLastError());
+    return TSDF_OK;
+}
+
+// One masked frame into one volume: tile table of depth x mask, then the class of every workgroup of the coming launch
+// (grid nbx x nby x nz; rows_per_wg as classify_workgroups takes it).  Sets p.wg_class.
+int classify_single(tsdf_volume *v, tsdfk::IntegrateParams &p, int nbx, int nby, int nz, int rows_per_wg)
+{
+    const size_t per = tile_table_elems_host(p.tiles_w, p.tiles_h);
+    if (!v->d_tiles) HIP_TRY(hipMalloc((void **)&v->d_tiles, tsdfk::kMaxFramesPerLaunch * per * sizeof(float2)));
+    const size_t n_wg = (size_t)nbx * nby * nz;
+    if (v->wg_class_bytes < n_wg) {
+        if (v->d_wg_class) HIP_TRY(hipFree(v->d_wg_class));
+        v->d_wg_class = nullptr;
+        v->wg_class_bytes = 0;
+        HIP_TRY(hipMalloc((void **)&v->d_wg_class, n_wg));
+        v->wg_class_bytes = n_wg;
+    }
+    const float *d = p.depth;
+    const uint8_t *m = p.mask;
+    int rc = build_tile_tables(v->stream, v->cfg, p, &d, &m, 1, v->d_tiles);
+    if (rc) return rc;
+    tsdfk::FramePose pose;
+    pose_from_params(pose, p);
+    pose.tiles = v->d_tiles;
+    hipLaunchKernelGGL(tsdfk::classify_workgroups, dim3((unsigned)((n_wg + 255) / 256)), dim3(256), 0, v->stream, p, pose,
+                       v->d_wg_class, nbx, nby, nz, rows_per_wg);
+    HIP_TRY(hipGetLastError());
+    p.wg_class = v->d_wg_class;
+    return TSDF_OK;
 }
 
 // Kernel variants (tsdf_set_kernel_variant):
@@ -306,7 +388,17 @@ int launch_integrate(tsdf_volume *v, const float *depth_dev, const uint8_t *mask
             else hipLaunchKernelGGL((tsdfk::integrate_rows<1, false>), grid, block, 0, v->stream, p);
         }
     } else if (mask_dev) {
-        launch_tile<2, true, true, true, true, false, true>(v, p);  // masked fusion uses the default configuration
+        // masked fusion uses the default configuration; per-object volumes see their instance only, so the workgroups
+        // the tile table of depth x mask proves untouched are told to leave (variant 7: never)
+        const dim3 grid((p.xgroups + 63) / 64, (p.dim_y + 7) / 8, p.nz);
+        if (v->variant != 7 && tiles_fit(p)) {
+            int rc = classify_single(v, p, (int)grid.x, (int)grid.y, (int)grid.z, 8);
+            if (rc) return rc;
+            hipLaunchKernelGGL((tsdfk::integrate_tile<2, true, true, true, true, false, true, false, true>), grid, dim3(64, 4, 1), 0,
+                               v->stream, p);
+        } else {
+            launch_tile<2, true, true, true, true, false, true>(v, p);
+        }
     } else if (variant >= 32) {
         switch (variant - 32) {
 #define SUM_CASE(code, R, N, S, E) case code: launch_tile<R, true, N, false, S, E>(v, p); break;
@@ -365,17 +457,9 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
     const int nz = c.z_end - c.z_begin;
     if (nz == 0 || n == 0) return TSDF_OK;
     auto fill_pose = [&](tsdfk::FramePose &fp, int f) {
-        const tsdfk::IntegrateParams q = make_params(v, depth_dev[f], masks_dev ? masks_dev[f] : nullptr, c2b + 16 * f, 4);
-        fp.depth = q.depth; fp.mask = q.mask;
-        fp.rx0 = q.rx0; fp.rx1 = q.rx1; fp.rx2 = q.rx2;
-        fp.ry0 = q.ry0; fp.ry1 = q.ry1; fp.ry2 = q.ry2;
-        fp.rz0 = q.rz0; fp.rz1 = q.rz1; fp.rz2 = q.rz2;
-        fp.tx = q.tx; fp.ty = q.ty; fp.tz = q.tz;
-        fp.fast_ok = q.fast_ok; fp.cz_margin = q.cz_margin;
+        pose_from_params(fp, make_params(v, depth_dev[f], masks_dev ? masks_dev[f] : nullptr, c2b + 16 * f, 4));
         fp.label_im = label_ims ? label_ims[f] : nullptr;
         fp.score_im = label_ims ? score_ims[f] : nullptr;
-        fp.tiles = nullptr;
-        fp.cz_short = q.cz_short; fp.cz_pad = q.cz_pad;
     };
     if (n == 1 && !label_ims) {   // pose by value: nothing to stage
         tsdfk::IntegrateParams common = make_params(v, depth_dev[0], nullptr, c2b, 4);
@@ -384,7 +468,15 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
         std::memcpy(v->last_cam2base, c2b, sizeof v->last_cam2base);
         v->flags_known_zero = false;
         dim3 block(64, 4, 1);
-        if (v->flat) {
+        if (v->flat && pose.mask != nullptr && v->variant != 7 && tiles_fit(common)) {
+            // one masked frame into a flat-mapped volume (the reference's 200^3 object grids): classified per workgroup
+            dim3 grid((v->chunks_per_slice + 3) / 4, 1, nz);
+            tsdfk::IntegrateParams cp = make_params(v, depth_dev[0], pose.mask, c2b, 4);
+            int rc = classify_single(v, cp, (int)grid.x, 1, nz, 0);
+            if (rc) return rc;
+            common.wg_class = cp.wg_class;
+            hipLaunchKernelGGL((tsdfk::integrate_multi_single<true, true, true>), grid, block, 0, v->stream, common, pose);
+        } else if (v->flat) {
             dim3 grid((v->chunks_per_slice + 3) / 4, 1, nz);
             hipLaunchKernelGGL((tsdfk::integrate_multi_single<true, true>), grid, block, 0, v->stream, common, pose);
         } else {
@@ -436,7 +528,7 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
                     return fail(TSDF_ERR_HIP, "claims read-back: hipEventQuery failed: %s", hipGetErrorString(qe));
                 }
             }
-            bool classify = (int64_t)mi.common.tiles_w * mi.common.tiles_h <= 8192 && v->variant != 7;
+            bool classify = tiles_fit(mi.common) && v->variant != 7;
             if (classify && v->variant != 8)
                 classify = !v->claims_known || v->claim_fraction >= 0.10 || v->launches_unclassified >= 7;
             v->launches_unclassified = classify ? 0 : v->launches_unclassified + 1;
@@ -452,22 +544,10 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
             }
             if (classify) {
                 // depth tile tables of the n frames (two small launches), then the kernel that consults them
-                auto levels = [](int n_) { int l = 0; while (n_ > 0) { ++l; n_ >>= 1; } return l; };
-                const size_t per_frame = (size_t)levels(mi.common.tiles_w) * levels(mi.common.tiles_h) *
-                                         mi.common.tiles_w * mi.common.tiles_h;
+                const size_t per_frame = tile_table_elems_host(mi.common.tiles_w, mi.common.tiles_h);
                 if (!v->d_tiles) HIP_TRY(hipMalloc((void **)&v->d_tiles, tsdfk::kMaxFramesPerLaunch * per_frame * sizeof(float2)));
-                tsdfk::TileSummaryParams tp;
-                for (int f = 0; f < tsdfk::kMaxFramesPerLaunch; ++f) {
-                    tp.depth[f] = depth_dev[f < n ? f : 0];
-                    tp.mask[f] = masks_dev ? masks_dev[f < n ? f : 0] : nullptr;
-                }
-                tp.tiles = v->d_tiles;
-                tp.H = c.im_height; tp.W = c.im_width; tp.tiles_w = mi.common.tiles_w; tp.tiles_h = mi.common.tiles_h;
-                tp.max_depth = c.max_depth;
-                hipLaunchKernelGGL(tsdfk::depth_tile_summary, dim3((unsigned)(mi.common.tiles_w * mi.common.tiles_h), n), dim3(64),
-                                   0, v->stream, tp);
-                hipLaunchKernelGGL(tsdfk::tile_sparse_table, dim3(n), dim3(256), 0, v->stream, v->d_tiles, mi.common.tiles_w,
-                                   mi.common.tiles_h);
+                int rc = build_tile_tables(v->stream, c, mi.common, depth_dev, masks_dev, n, v->d_tiles);
+                if (rc) return rc;
                 for (int f = 0; f < n; ++f) mi.frames[f].tiles = v->d_tiles + (size_t)f * per_frame;
                 for (int f = n; f < tsdfk::kMaxFramesPerLaunch; ++f) mi.frames[f] = mi.frames[0];
             }
@@ -767,6 +847,7 @@ int tsdf_destroy(tsdf_volume *v)
     if (v->d_bp) (void)hipFree(v->d_bp);
     if (v->d_scratch) (void)hipFree(v->d_scratch);
     if (v->d_list) (void)hipFree(v->d_list);
+    if (v->d_wg_class) (void)hipFree(v->d_wg_class);
     if (v->d_flags) (void)hipFree(v->d_flags);
     if (v->d_tiles) (void)hipFree(v->d_tiles);
     if (v->d_claims) (void)hipFree(v->d_claims);
@@ -1302,6 +1383,8 @@ int tsdf_batch_destroy(tsdf_batch *b)
         if (b->slot_done[i]) (void)hipEventDestroy(b->slot_done[i]);
     }
     if (b->d_slice_map) (void)hipFree(b->d_slice_map);
+    if (b->d_tiles) (void)hipFree(b->d_tiles);
+    if (b->d_wg_class) (void)hipFree(b->d_wg_class);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
     return TSDF_OK;
@@ -1322,6 +1405,7 @@ int tsdf_batch_create(const tsdf_config *cfgs, int32_t n, tsdf_batch **out)
     if (!b) return fail(TSDF_ERR_INVALID, "tsdf_batch_create: out of host memory");
     b->device = cfgs[0].device;
     b->stream = nullptr; b->d_slice_map = nullptr; b->slot_next = 0;
+    b->d_tiles = nullptr; b->tiles_per_object = 0; b->d_wg_class = nullptr;
     b->total_slices = b->max_blocks = 0;
     for (int i = 0; i < kStageSlots; ++i) {
         b->h_params[i] = nullptr; b->d_params[i] = nullptr; b->h_poses[i] = nullptr; b->d_poses[i] = nullptr;
@@ -1394,20 +1478,42 @@ int tsdf_batch_integrate_device(tsdf_batch *b, const float *depth_dev, const uin
         std::memcpy(v->last_cam2base, c2b, sizeof c2b);
         const tsdfk::IntegrateParams q = make_params(v, depth_dev, masks_dev ? masks_dev[i] : nullptr, c2b, 4);
         b->h_params[s][i] = q;
-        tsdfk::FramePose &fp = b->h_poses[s][i];
-        fp.depth = q.depth; fp.mask = q.mask;
-        fp.rx0 = q.rx0; fp.rx1 = q.rx1; fp.rx2 = q.rx2;
-        fp.ry0 = q.ry0; fp.ry1 = q.ry1; fp.ry2 = q.ry2;
-        fp.rz0 = q.rz0; fp.rz1 = q.rz1; fp.rz2 = q.rz2;
-        fp.tx = q.tx; fp.ty = q.ty; fp.tz = q.tz;
-        fp.fast_ok = q.fast_ok; fp.cz_margin = q.cz_margin;
+        pose_from_params(b->h_poses[s][i], q);
         v->flags_known_zero = false;           // the batched kernel maintains the summary
+    }
+    // Instance masks given: every object sees only its own instance (ref: src/Engine.cpp:192-193), so most workgroups of
+    // most objects see nothing.  Tile tables of depth x mask per object, the class of every workgroup of the launch
+    // (one thread each), and the launch's untouched workgroups leave at once.  (First volume on variant 7: never.)
+    bool any_mask = false;
+    for (int i = 0; i < n && masks_dev; ++i) any_mask = any_mask || masks_dev[i] != nullptr;
+    bool same_range = true;   // one tile table per object, but all made with one depth-range test
+    for (int i = 1; i < n; ++i) same_range = same_range && b->vols[i]->cfg.max_depth == b->vols[0]->cfg.max_depth;
+    const bool classify = any_mask && same_range && b->vols[0]->variant != 7 && tiles_fit(b->h_params[s][0]);
+    if (classify) {
+        const size_t per = tile_table_elems_host(b->h_params[s][0].tiles_w, b->h_params[s][0].tiles_h);
+        if (!b->d_tiles) {
+            HIP_TRY(hipMalloc((void **)&b->d_tiles, (size_t)n * per * sizeof(float2)));
+            HIP_TRY(hipMalloc((void **)&b->d_wg_class, (size_t)b->max_blocks * b->total_slices));
+            b->tiles_per_object = per;
+        }
+        std::vector<const float *> depths((size_t)n, depth_dev);
+        int rc = build_tile_tables(b->stream, b->vols[0]->cfg, b->h_params[s][0], depths.data(), masks_dev, n, b->d_tiles);
+        if (rc) return rc;
+        for (int i = 0; i < n; ++i) b->h_poses[s][i].tiles = b->d_tiles + (size_t)i * per;
     }
     HIP_TRY(hipMemcpyAsync(b->d_params[s], b->h_params[s], n * sizeof(tsdfk::IntegrateParams), hipMemcpyHostToDevice, b->stream));
     HIP_TRY(hipMemcpyAsync(b->d_poses[s], b->h_poses[s], n * sizeof(tsdfk::FramePose), hipMemcpyHostToDevice, b->stream));
     dim3 block(64, 4, 1), grid(b->max_blocks, 1, b->total_slices);
-    hipLaunchKernelGGL((tsdfk::integrate_multi_batched<true>), grid, block, 0, b->stream, b->d_params[s], b->d_poses[s],
-                       b->d_slice_map);
+    if (classify) {
+        const size_t n_wg = (size_t)b->max_blocks * b->total_slices;
+        hipLaunchKernelGGL(tsdfk::classify_workgroups_batched, dim3((unsigned)((n_wg + 255) / 256)), dim3(256), 0, b->stream,
+                           b->d_params[s], b->d_poses[s], b->d_slice_map, b->d_wg_class, b->max_blocks, b->total_slices);
+        hipLaunchKernelGGL((tsdfk::integrate_multi_batched<true, true>), grid, block, 0, b->stream, b->d_params[s], b->d_poses[s],
+                           b->d_slice_map, b->d_wg_class);
+    } else {
+        hipLaunchKernelGGL((tsdfk::integrate_multi_batched<true, false>), grid, block, 0, b->stream, b->d_params[s], b->d_poses[s],
+                           b->d_slice_map, (const uint8_t *)nullptr);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(b->slot_done[s], b->stream));
     b->slot_used[s] = true;

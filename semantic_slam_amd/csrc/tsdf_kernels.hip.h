@@ -67,6 +67,11 @@ struct IntegrateParams {
     // one word per classifying launch: (workgroup-frames claimed as free space << 32) | workgroup-frames skipped; the
     // host reads it back asynchronously and decides whether the next launch classifies at all (null = not counted)
     unsigned long long *claim_counter;
+    // One-frame launches of masked / per-object volumes: class of every workgroup's patch for this frame, decided
+    // by a small kernel ahead of the launch (tsdf_multiframe.hip.h, classify_workgroups): 0 = per-voxel path,
+    // 1 = every voxel updated with dist = 1, 2 = no voxel updated.  Index = linear workgroup id of the launch.
+    // Null = not classified.
+    const uint8_t *wg_class;
 };
 
 // Terms of the camera-frame point that do not depend on x (shared by a lane's voxels).
@@ -620,10 +625,16 @@ __device__ __forceinline__ void integrate_tile_body(const IntegrateParams &p, co
     }
 }
 
+// CLS: the launch comes with a workgroup class table (IntegrateParams::wg_class); a workgroup whose whole patch
+// the depth tile table proved untouched by this frame leaves at once (masked per-object volumes: most of them).
 template <int R, bool ELIDE, bool NT, bool MASKED, bool SUM = false, bool EARLY = false, bool FAST = false,
-          bool LDSD = false>
+          bool LDSD = false, bool CLS = false>
 __global__ __launch_bounds__(256) void integrate_tile(IntegrateParams p)
 {
+    if constexpr (CLS) {
+        const unsigned id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (p.wg_class[id] == 2) return;   // wave-uniform (scalar load): nothing to update anywhere in the patch
+    }
     integrate_tile_body<R, ELIDE, NT, MASKED ? 1 : 0, SUM, EARLY, FAST, LDSD>(p, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 

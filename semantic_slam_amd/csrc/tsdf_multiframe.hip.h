@@ -198,6 +198,56 @@ __device__ __forceinline__ int classify_patch(const IntegrateParams &p, const Fr
     return 0;
 }
 
+// One-frame launches: the class of every workgroup's patch, one THREAD per workgroup, ahead of the Integrate launch
+// (a 200^3 volume has 7 813 workgroups: this kernel is noise).  The Integrate kernel then reads one byte per
+// workgroup through a scalar load.  rows_per_wg > 0: row mapping (256 x rows_per_wg voxels per workgroup, grid =
+// (x blocks, y blocks, slices)); rows_per_wg == 0: flat mapping (1024 consecutive voxels, grid = (blocks, 1, slices)).
+__device__ __forceinline__ int classify_wg_patch(const IntegrateParams &p, const FramePose *pose, int bx, int by, int lz,
+                                                 int rows_per_wg)
+{
+    int xa, xb, ya, yb;
+    if (rows_per_wg == 0) {
+        const int n_vox = p.quads_per_slice * 4;
+        const int i0 = bx * 1024;
+        if (i0 >= n_vox) return 2;                       // a block past the end of the slice: nothing there
+        const int i1 = min(i0 + 1023, n_vox - 1);
+        ya = i0 / p.dim_x;
+        yb = i1 / p.dim_x;
+        xa = ya == yb ? i0 - ya * p.dim_x : 0;
+        xb = ya == yb ? i1 - yb * p.dim_x : p.dim_x - 1;
+    } else {
+        xa = bx * 256;
+        ya = by * rows_per_wg;
+        if (xa >= p.dim_x || ya >= p.dim_y) return 2;
+        xb = min(xa + 255, p.dim_x - 1);
+        yb = min(ya + rows_per_wg - 1, p.dim_y - 1);
+    }
+    return classify_patch(p, pose, xa, xb, ya, yb, p.z_begin + lz);
+}
+
+__global__ __launch_bounds__(256) void classify_workgroups(IntegrateParams p, FramePose pose, uint8_t *cls, int nbx, int nby,
+                                                           int nz, int rows_per_wg)
+{
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= nbx * nby * nz) return;
+    const int bx = id % nbx, t = id / nbx;
+    cls[id] = (uint8_t)classify_wg_patch(p, &pose, bx, t % nby, t / nby, rows_per_wg);
+}
+
+// the batched form: slice_map[z] = {object, slice}; params / poses per object; flat mapping; grid (max_blocks, 1, total_slices)
+__global__ __launch_bounds__(256) void classify_workgroups_batched(const IntegrateParams *__restrict__ params,
+                                                                   const FramePose *__restrict__ poses,
+                                                                   const int2 *__restrict__ slice_map, uint8_t *cls,
+                                                                   int max_blocks, int total_slices)
+{
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= max_blocks * total_slices) return;
+    const int bx = id % max_blocks, z = id / max_blocks;
+    const int2 m = slice_map[z];
+    const IntegrateParams p = params[m.x];
+    cls[id] = (uint8_t)classify_wg_patch(p, poses + m.x, bx, 0, m.y, 0);
+}
+
 // Slab arrays of the per-voxel label state (tsdf_labels.hip.h), for the LABELS kernels.
 struct LabelState {
     uint16_t *label;
@@ -640,10 +690,19 @@ __global__ __launch_bounds__(256) void integrate_multi_xcd(MultiParams mp)
 
 // One frame, pose by value (no frame block in memory to stage): what a single tsdf_integrate* call
 // on a volume served by the flat mapping launches.
-template <bool NT, bool FLAT>
+// CLS: with a workgroup class table (IntegrateParams::wg_class, classify_workgroups): skipped workgroups leave at
+// once, free-space ones only add to their weights.
+template <bool NT, bool FLAT, bool CLS = false>
 __global__ __launch_bounds__(256) void integrate_multi_single(IntegrateParams p, FramePose pose)
 {
-    multi_body<1, NT, FLAT>(p, &pose, 1, blockIdx.x, blockIdx.y, blockIdx.z);
+    if constexpr (CLS) {
+        const unsigned id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const unsigned c = p.wg_class[id];
+        if (c == 2u) return;
+        multi_body<1, NT, FLAT, false, true, true>(p, &pose, 1, blockIdx.x, blockIdx.y, blockIdx.z, LabelState(), c == 1u ? 1u : 0u, 0u);
+    } else {
+        multi_body<1, NT, FLAT>(p, &pose, 1, blockIdx.x, blockIdx.y, blockIdx.z);
+    }
 }
 
 // Many volumes, one frame, one launch (the reference's real usage: one small TSDF per object
@@ -652,14 +711,25 @@ __global__ __launch_bounds__(256) void integrate_multi_single(IntegrateParams p,
 // its own base frame); slice_map[z] = {object, slice within it} for every slice of every object;
 // grid = (max blocks per slice, 1, total slices).  Flat mapping: object grids are small and rarely
 // 256 wide.  The blocks are read through a wave-uniform index (scalar loads).
-template <bool NT>
+// wg_class (may be null): class of every workgroup of this launch for this frame (classify_workgroups_batched):
+// per-object volumes are fed depth x their instance mask, so most of their workgroups see nothing and leave at once.
+template <bool NT, bool CLS>
 __global__ __launch_bounds__(256) void integrate_multi_batched(const IntegrateParams *__restrict__ params,
                                                                const FramePose *__restrict__ poses,
-                                                               const int2 *__restrict__ slice_map)
+                                                               const int2 *__restrict__ slice_map,
+                                                               const uint8_t *__restrict__ wg_class)
 {
+    unsigned c = 0u;
+    if constexpr (CLS) {
+        c = wg_class[blockIdx.x + gridDim.x * blockIdx.z];
+        if (c == 2u) return;
+    }
     const int2 m = slice_map[blockIdx.z];
     const IntegrateParams p = params[m.x];
-    multi_body<1, NT, true>(p, poses + m.x, 1, blockIdx.x, 0, m.y);
+    if constexpr (CLS)
+        multi_body<1, NT, true, false, true, true>(p, poses + m.x, 1, blockIdx.x, 0, m.y, LabelState(), c == 1u ? 1u : 0u, 0u);
+    else
+        multi_body<1, NT, true>(p, poses + m.x, 1, blockIdx.x, 0, m.y);
 }
 
 }  // namespace tsdfk

@@ -1,5 +1,11 @@
-"""Development probe: n object volumes of the reference's default size (200^3 @ 4 mm), one frame --
-one batched launch against n per-volume launches.   python tools/batch_time.py [n]"""
+"""Development probe: n object volumes of the reference's default size (200^3 @ 4 mm), one frame per call -- the
+reference's real call shape (one TSDF per object instance fed depth x its instance mask, ref: src/Engine.cpp:172-233,
+src/Object.cpp:67) -- as one batched launch and as n per-volume launches, each with and without the per-workgroup
+classification of masked frames (kernel variant 7 switches it off).
+
+    python tools/batch_time.py [--n 16] [--edge 200] [--masks instance|full|none]
+"""
+import argparse
 import os
 import sys
 import time
@@ -10,42 +16,74 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from semantic_slam_amd import capi, synth  # noqa: E402
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-E = int(sys.argv[2]) if len(sys.argv) > 2 else 200      # grid edge of every object volume
-use_masks = not (len(sys.argv) > 3 and sys.argv[3] == "nomask")
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=16)
+ap.add_argument("--edge", type=int, default=200)
+ap.add_argument("--masks", default="instance", choices=["instance", "full", "none"])
+ap.add_argument("--frames", type=int, default=200)
+args = ap.parse_args()
+n, E = args.n, args.edge
 rng = np.random.default_rng(0)
-cfgs = []
+vs = 0.8 / E
+cfgs, masks = [], []
+K = synth.TUM_K
 for i in range(n):
-    o = np.array([-0.4 + rng.uniform(-0.2, 0.2), -0.4 + rng.uniform(-0.2, 0.2), 0.7 + rng.uniform(0, 0.5)], np.float32)
-    cfgs.append(capi.make_config((E, E, E), 0.8 / E, o, vol_id=i))
+    o = np.array([-0.4 + rng.uniform(-0.3, 0.3), -0.4 + rng.uniform(-0.25, 0.25), 0.7 + rng.uniform(0, 0.8)], np.float32)
+    cfgs.append(capi.make_config((E, E, E), vs, o, vol_id=i))
+    m = np.zeros((480, 640), np.uint8)
+    if args.masks == "full":
+        m[:] = 255
+    elif args.masks == "instance":
+        # the instance: a 0.5 m box around the volume's centre as the first camera sees it
+        c = o + 0.4
+        u0, u1 = K[0] * (c[0] - 0.25) / c[2] + K[2], K[0] * (c[0] + 0.25) / c[2] + K[2]
+        v0, v1 = K[4] * (c[1] - 0.25) / c[2] + K[5], K[4] * (c[1] + 0.25) / c[2] + K[5]
+        m[max(0, int(v0)):max(0, min(480, int(v1))), max(0, int(u0)):max(0, min(640, int(u1)))] = 255
+    masks.append(m)
 scene = synth.SurfScene((200, 200, 200), 0.004, np.array([-0.4, -0.4, 0.7], np.float32))
 depth = torch.from_numpy(scene.depth(scene.pose(0, 8))).cuda()
-mask = torch.full((480, 640), 255, dtype=torch.uint8).cuda()
+m_dev = [torch.from_numpy(m).cuda() for m in masks]
+ptrs = None if args.masks == "none" else [m.data_ptr() for m in m_dev]
 poses = [scene.pose(k, 8) for k in range(8)]
-frames = 200
-with capi.Batch(cfgs) as batch:
-    ptrs = [mask.data_ptr()] * n if use_masks else None
+frames = args.frames
+cover = float(np.mean([m.mean() / 255.0 for m in masks]))
+vox = n * E ** 3
+print(f"{n} volumes of {E}^3, masks: {args.masks} (mean coverage {cover:.2f} of the image)")
+for cls in (True, False):
+    with capi.Batch(cfgs) as batch:
+        batch.volumes[0].set_kernel_variant(0 if cls else 7)
+        for k in range(10):
+            batch.integrate_device(depth.data_ptr(), ptrs, poses[k % 8])
+        batch.sync()
+        t0 = time.perf_counter()
+        for k in range(frames):
+            batch.integrate_device(depth.data_ptr(), ptrs, poses[k % 8])
+        batch.sync()
+        tb = (time.perf_counter() - t0) / frames
+        upd = sum(float(v.download()[1].sum()) for v in batch.volumes) / (frames + 10)
+    print(f"  batched launch, classification {'on ' if cls else 'off'}: {tb * 1e3:.3f} ms/frame ({vox / tb / 1e6:.0f} Mvox/s), "
+          f"{upd / vox:.3f} of the voxels updated per frame", flush=True)
+for cls in (True, False):
+    vols = [capi.Volume(c) for c in cfgs]
+    for v in vols:
+        v.set_kernel_variant(0 if cls else 7)
+
+    def one(k):
+        for i, v in enumerate(vols):
+            if ptrs is None:
+                v.integrate_device(depth.data_ptr(), poses[k % 8])
+            else:
+                v.integrate_masked_device(depth.data_ptr(), ptrs[i], poses[k % 8])
     for k in range(10):
-        batch.integrate_device(depth.data_ptr(), ptrs, poses[k % 8])
-    batch.sync()
+        one(k)
+    for v in vols:
+        v.sync()
     t0 = time.perf_counter()
     for k in range(frames):
-        batch.integrate_device(depth.data_ptr(), ptrs, poses[k % 8])
-    batch.sync()
-    tb = (time.perf_counter() - t0) / frames
-vols = [capi.Volume(c) for c in cfgs]
-for k in range(10):
+        one(k)
     for v in vols:
-        v.integrate_masked_device(depth.data_ptr(), mask.data_ptr(), poses[k % 8]) if use_masks else v.integrate_device(depth.data_ptr(), poses[k % 8])
-for v in vols:
-    v.sync()
-t0 = time.perf_counter()
-for k in range(frames):
+        v.sync()
+    ts = (time.perf_counter() - t0) / frames
     for v in vols:
-        v.integrate_masked_device(depth.data_ptr(), mask.data_ptr(), poses[k % 8]) if use_masks else v.integrate_device(depth.data_ptr(), poses[k % 8])
-for v in vols:
-    v.sync()
-ts = (time.perf_counter() - t0) / frames
-vox = n * E ** 3
-print(f"{n} volumes of {E}^3{'' if use_masks else ' (no masks)'}: batched {tb * 1e3:.3f} ms/frame ({vox / tb / 1e6:.0f} Mvox/s), "
-      f"per-volume launches {ts * 1e3:.3f} ms/frame ({vox / ts / 1e6:.0f} Mvox/s), speed-up {ts / tb:.2f}x")
+        v.close()
+    print(f"  per-volume launches, classification {'on ' if cls else 'off'}: {ts * 1e3:.3f} ms/frame ({vox / ts / 1e6:.0f} Mvox/s)", flush=True)
