@@ -70,6 +70,9 @@ struct tsdf_volume {
     hipEvent_t stage_done[kStageSlots];
     bool stage_used[kStageSlots];
     int stage_next;
+    // the H2D copy of a frame runs on its own stream and overlaps the previous frame's kernel; the kernel waits for it
+    hipStream_t copy_stream;
+    hipEvent_t copy_done[kStageSlots];
     int variant;
     // per-launch frame blocks of integrate_multi: pinned host ring -> device ring (allocated on first use)
     tsdfk::FramePose *h_frames[kStageSlots];
@@ -243,6 +246,18 @@ size_t tile_table_elems_host(int tiles_w, int tiles_h)
 
 bool tiles_fit(const tsdfk::IntegrateParams &p) { return (int64_t)p.tiles_w * p.tiles_h <= 8192; }
 
+// One-frame masked launches are classified per workgroup when the launch is large enough to repay the three small
+// dependent dispatches ahead of it (tile summary, sparse table, class table: ~25 us on the stream).  Measured
+// (tools/batch_time.py, instance masks over 12 % of the image): 16 x 200^3 batched 0.274 -> 0.204 ms per frame, one
+// 400^3 volume 0.095 -> 0.075; but 4 x 200^3 batched 0.083 -> 0.094 and one 200^3 volume 0.016 -> 0.026.
+// Variant 8 classifies regardless (tests), 7 never.
+constexpr int64_t kClassifyMinVoxels = 48000000;
+bool classify_one_frame(const tsdf_volume *v, int64_t launch_voxels)
+{
+    if (v->variant == 7) return false;
+    return v->variant == 8 || launch_voxels >= kClassifyMinVoxels;
+}
+
 // Depth tile tables (summary + sparse table, tsdf_multiframe.hip.h) of n images depth[i] x mask[i] into tables[i], queued
 // on `stream`; two small launches per 32 images.
 int build_tile_tables(hipStream_t stream, const tsdf_config &c, const tsdfk::IntegrateParams &p, const float *const *depth,
@@ -259,8 +274,9 @@ int build_tile_tables(hipStream_t stream, const tsdf_config &c, const tsdfk::Int
         tp.tiles = tables + (size_t)k * per;
         tp.H = c.im_height; tp.W = c.im_width; tp.tiles_w = p.tiles_w; tp.tiles_h = p.tiles_h;
         tp.max_depth = c.max_depth;
-        hipLaunchKernelGGL(tsdfk::depth_tile_summary, dim3((unsigned)(p.tiles_w * p.tiles_h), m), dim3(64), 0, stream, tp);
-        hipLaunchKernelGGL(tsdfk::tile_sparse_table, dim3(m), dim3(256), 0, stream, tp.tiles, p.tiles_w, p.tiles_h);
+        hipLaunchKernelGGL(tsdfk::depth_tile_summary, dim3((unsigned)((p.tiles_w * p.tiles_h + 3) / 4), m), dim3(64, 4), 0, stream, tp);
+        hipLaunchKernelGGL(tsdfk::tile_sparse_table, dim3((unsigned)tile_levels_host(p.tiles_w), m), dim3(256), 0, stream, tp.tiles,
+                           p.tiles_w, p.tiles_h);
     }
     HIP_TRY(hipGetLastError());
     return TSDF_OK;
@@ -391,7 +407,7 @@ int launch_integrate(tsdf_volume *v, const float *depth_dev, const uint8_t *mask
         // masked fusion uses the default configuration; per-object volumes see their instance only, so the workgroups
         // the tile table of depth x mask proves untouched are told to leave (variant 7: never)
         const dim3 grid((p.xgroups + 63) / 64, (p.dim_y + 7) / 8, p.nz);
-        if (v->variant != 7 && tiles_fit(p)) {
+        if (classify_one_frame(v, v->n_vox) && tiles_fit(p)) {
             int rc = classify_single(v, p, (int)grid.x, (int)grid.y, (int)grid.z, 8);
             if (rc) return rc;
             hipLaunchKernelGGL((tsdfk::integrate_tile<2, true, true, true, true, false, true, false, true>), grid, dim3(64, 4, 1), 0,
@@ -468,7 +484,7 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
         std::memcpy(v->last_cam2base, c2b, sizeof v->last_cam2base);
         v->flags_known_zero = false;
         dim3 block(64, 4, 1);
-        if (v->flat && pose.mask != nullptr && v->variant != 7 && tiles_fit(common)) {
+        if (v->flat && pose.mask != nullptr && classify_one_frame(v, v->n_vox) && tiles_fit(common)) {
             // one masked frame into a flat-mapped volume (the reference's 200^3 object grids): classified per workgroup
             dim3 grid((v->chunks_per_slice + 3) / 4, 1, nz);
             tsdfk::IntegrateParams cp = make_params(v, depth_dev[0], pose.mask, c2b, 4);
@@ -803,6 +819,8 @@ int tsdf_create(const tsdf_config *cfg, tsdf_volume **out)
     if ((e = hipStreamCreateWithFlags(&v->own_stream, hipStreamNonBlocking)) != hipSuccess)
         return cleanup(fail(TSDF_ERR_HIP, "tsdf_create: hipStreamCreate: %s", hipGetErrorString(e)));
     v->stream = v->own_stream;
+    if ((e = hipStreamCreateWithFlags(&v->copy_stream, hipStreamNonBlocking)) != hipSuccess)
+        return cleanup(fail(TSDF_ERR_HIP, "tsdf_create: hipStreamCreate: %s", hipGetErrorString(e)));
     size_t bytes = (size_t)(v->n_vox > 0 ? v->n_vox : 1) * sizeof(float);
     if ((e = hipMalloc((void **)&v->d_tsdf, bytes)) != hipSuccess ||
         (e = hipMalloc((void **)&v->d_weight, bytes)) != hipSuccess)
@@ -817,7 +835,8 @@ int tsdf_create(const tsdf_config *cfg, tsdf_volume **out)
     for (int i = 0; i < kStageSlots; ++i) {
         if ((e = hipHostMalloc((void **)&v->h_stage[i], img, hipHostMallocDefault)) != hipSuccess ||
             (e = hipMalloc((void **)&v->d_stage[i], img)) != hipSuccess ||
-            (e = hipEventCreateWithFlags(&v->stage_done[i], hipEventDisableTiming)) != hipSuccess)
+            (e = hipEventCreateWithFlags(&v->stage_done[i], hipEventDisableTiming)) != hipSuccess ||
+            (e = hipEventCreateWithFlags(&v->copy_done[i], hipEventDisableTiming)) != hipSuccess)
             return cleanup(fail(TSDF_ERR_HIP, "tsdf_create: staging alloc: %s", hipGetErrorString(e)));
     }
     if ((rc = fill(v)) != TSDF_OK) return cleanup(rc);
@@ -831,7 +850,9 @@ int tsdf_destroy(tsdf_volume *v)
     (void)hipSetDevice(v->cfg.device);
     if (v->own_stream) (void)hipStreamSynchronize(v->own_stream);
     if (v->stream && v->stream != v->own_stream) (void)hipStreamSynchronize(v->stream);
+    if (v->copy_stream) (void)hipStreamSynchronize(v->copy_stream);
     for (int i = 0; i < kStageSlots; ++i) {
+        if (v->copy_done[i]) (void)hipEventDestroy(v->copy_done[i]);
         if (v->stage_done[i]) (void)hipEventDestroy(v->stage_done[i]);
         if (v->h_stage[i]) (void)hipHostFree(v->h_stage[i]);
         if (v->d_stage[i]) (void)hipFree(v->d_stage[i]);
@@ -856,6 +877,7 @@ int tsdf_destroy(tsdf_volume *v)
     if (v->d_shortcut_stats) (void)hipFree(v->d_shortcut_stats);
     if (v->d_tsdf) (void)hipFree(v->d_tsdf);
     if (v->d_weight) (void)hipFree(v->d_weight);
+    if (v->copy_stream) (void)hipStreamDestroy(v->copy_stream);
     if (v->own_stream) (void)hipStreamDestroy(v->own_stream);
     delete v;
     return TSDF_OK;
@@ -879,7 +901,10 @@ int tsdf_integrate(tsdf_volume *v, const float *depth_host, const float cam2worl
     if (v->stage_used[s]) HIP_TRY(hipEventSynchronize(v->stage_done[s]));  // slot's last kernel done
     size_t img = (size_t)v->cfg.im_height * v->cfg.im_width * sizeof(float);
     std::memcpy(v->h_stage[s], depth_host, img);  // caller may free depth_host after we return
-    HIP_TRY(hipMemcpyAsync(v->d_stage[s], v->h_stage[s], img, hipMemcpyHostToDevice, v->stream));
+    // copy on the copy stream (it overlaps the kernel of the previous frame), kernel after it
+    HIP_TRY(hipMemcpyAsync(v->d_stage[s], v->h_stage[s], img, hipMemcpyHostToDevice, v->copy_stream));
+    HIP_TRY(hipEventRecord(v->copy_done[s], v->copy_stream));
+    HIP_TRY(hipStreamWaitEvent(v->stream, v->copy_done[s], 0));
     float c2b[16];
     compose_cam2base(v, cam2world, c2b);
     rc = launch_integrate(v, v->d_stage[s], nullptr, c2b);
@@ -917,7 +942,9 @@ int tsdf_integrate_u16(tsdf_volume *v, const uint16_t *raw_host, float depth_fac
     const size_t px = (size_t)v->cfg.im_height * v->cfg.im_width;
     if (!v->d_raw[s]) HIP_TRY(hipMalloc((void **)&v->d_raw[s], px * sizeof(uint16_t)));
     std::memcpy(v->h_stage[s], raw_host, px * sizeof(uint16_t));  // the float-sized pinned slot holds it
-    HIP_TRY(hipMemcpyAsync(v->d_raw[s], v->h_stage[s], px * sizeof(uint16_t), hipMemcpyHostToDevice, v->stream));
+    HIP_TRY(hipMemcpyAsync(v->d_raw[s], v->h_stage[s], px * sizeof(uint16_t), hipMemcpyHostToDevice, v->copy_stream));
+    HIP_TRY(hipEventRecord(v->copy_done[s], v->copy_stream));
+    HIP_TRY(hipStreamWaitEvent(v->stream, v->copy_done[s], 0));
     rc = tsdf_convert_depth_u16(v, v->d_raw[s], v->d_stage[s], depth_factor, row_step, col_step);
     if (rc) return rc;
     float c2b[16];
@@ -1488,7 +1515,9 @@ int tsdf_batch_integrate_device(tsdf_batch *b, const float *depth_dev, const uin
     for (int i = 0; i < n && masks_dev; ++i) any_mask = any_mask || masks_dev[i] != nullptr;
     bool same_range = true;   // one tile table per object, but all made with one depth-range test
     for (int i = 1; i < n; ++i) same_range = same_range && b->vols[i]->cfg.max_depth == b->vols[0]->cfg.max_depth;
-    const bool classify = any_mask && same_range && b->vols[0]->variant != 7 && tiles_fit(b->h_params[s][0]);
+    int64_t launch_voxels = 0;
+    for (tsdf_volume *v : b->vols) launch_voxels += v->n_vox;
+    const bool classify = any_mask && same_range && classify_one_frame(b->vols[0], launch_voxels) && tiles_fit(b->h_params[s][0]);
     if (classify) {
         const size_t per = tile_table_elems_host(b->h_params[s][0].tiles_w, b->h_params[s][0].tiles_h);
         if (!b->d_tiles) {

@@ -7,7 +7,8 @@
 // into n contiguous z-slabs (the layout is z-major, ref: src/tsdf.cu:52), one `tsdf_volume` handle each, slab i
 // on devices[i] with its own stream.
 //   * Integrate: the caller's depth frame is copied once into a pinned buffer every device can read, then fanned out
-//     with one hipMemcpyAsync per slab on that slab's stream, followed by that slab's kernel -- no host
+//     with one hipMemcpyAsync per slab on that slab's copy stream (it overlaps the slab's previous kernel), followed
+//     by that slab's kernel -- no host
 //     synchronisation between devices, no collective; every slab uses the GLOBAL z index, so the result is
 //     bit-identical to one handle holding the whole grid.
 //   * Extraction: the reference's surface rule is per voxel; zero crossings and the mesh take slice z_end from the
@@ -216,7 +217,9 @@ int tsdf_group_integrate(tsdf_group *g, const float *depth_host, const float cam
     std::memcpy(g->h_ring[s], depth_host, img);          // the caller may free depth_host after we return
     for (tsdf_volume *v : g->slabs) {
         HIP_TRY(hipSetDevice(v->cfg.device));
-        HIP_TRY(hipMemcpyAsync(v->d_stage[s], g->h_ring[s], img, hipMemcpyHostToDevice, v->stream));
+        HIP_TRY(hipMemcpyAsync(v->d_stage[s], g->h_ring[s], img, hipMemcpyHostToDevice, v->copy_stream));
+        HIP_TRY(hipEventRecord(v->copy_done[s], v->copy_stream));
+        HIP_TRY(hipStreamWaitEvent(v->stream, v->copy_done[s], 0));
         float c2b[16];
         compose_cam2base(v, cam2world, c2b);
         int rc = launch_integrate(v, v->d_stage[s], nullptr, c2b);

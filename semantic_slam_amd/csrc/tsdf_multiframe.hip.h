@@ -60,9 +60,11 @@ struct TileSummaryParams {
 __device__ __forceinline__ int tile_levels(int n) { return 32 - __clz(n); }   // floor(log2 n) + 1, n >= 1
 __device__ __forceinline__ size_t tile_table_elems(int tw, int th) { return (size_t)tile_levels(tw) * tile_levels(th) * tw * th; }
 
-__global__ __launch_bounds__(64) void depth_tile_summary(TileSummaryParams tp)
+// block = 64 x 4: one wavefront per tile, four tiles per workgroup; grid = (ceil(tiles / 4), frames)
+__global__ __launch_bounds__(256) void depth_tile_summary(TileSummaryParams tp)
 {
-    const int tile = blockIdx.x, f = blockIdx.y;
+    const int tile = blockIdx.x * 4 + threadIdx.y, f = blockIdx.y;
+    if (tile >= tp.tiles_w * tp.tiles_h) return;
     const int ty = tile / tp.tiles_w, tx = tile - ty * tp.tiles_w;
     const int lane = threadIdx.x;
     const int py = ty * kTile + (lane >> 2), px0 = tx * kTile + (lane & 3) * 4;
@@ -99,34 +101,49 @@ __global__ __launch_bounds__(64) void depth_tile_summary(TileSummaryParams tp)
     }
 }
 
-// One workgroup per frame builds the upper levels from level (0, 0): first along x, then along y.
+// The upper levels from level (0, 0), one workgroup per (x level j, frame): first level (0, j) straight from the base
+// tiles -- the combination over tiles tx .. min(tx + 2^j - 1, tw - 1) of each row (min and max are exact and
+// idempotent, so any evaluation order gives the same bits) -- kept in LDS, then, after ONE barrier, the levels (i, j)
+// from 2^i rows of it.  6 x n workgroups with one barrier each instead of one workgroup per frame walking through 29
+// dependent passes (55 us per launch: a third of a one-frame launch on a 200^3 volume).  Tables of more than
+// kTileLdsEntries tiles fall back to reading level (0, j) from memory after the barrier (same values).
+constexpr int kTileLdsEntries = 2048;   // float2: 16 KiB of LDS
+
 __global__ __launch_bounds__(256) void tile_sparse_table(float2 *tables, int tw, int th)
 {
     const int lj = tile_levels(tw), li = tile_levels(th), n = tw * th;
-    float2 *T = tables + (size_t)blockIdx.x * tile_table_elems(tw, th);
-    auto level = [&](int i, int j) { return T + (size_t)(i * lj + j) * n; };
-    for (int j = 1; j < lj; ++j) {
-        __syncthreads();
-        const float2 *src = level(0, j - 1);
-        float2 *dst = level(0, j);
-        const int step = 1 << (j - 1);
+    const int j = blockIdx.x;                      // this workgroup's x level
+    float2 *T = tables + (size_t)blockIdx.y * tile_table_elems(tw, th);
+    const float2 *base = T;
+    float2 *row_level = T + (size_t)j * n;         // level (0, j)
+    __shared__ float2 lds[kTileLdsEntries];
+    const bool in_lds = n <= kTileLdsEntries;
+    const int span = 1 << j;
+    for (int k = threadIdx.x; k < n; k += blockDim.x) {
+        const int ty = k / tw, tx = k - ty * tw;
+        const int last = min(tx + span - 1, tw - 1);
+        float2 acc = base[k];
+        for (int x = tx + 1; x <= last; ++x) {
+            const float2 b = base[ty * tw + x];
+            acc = make_float2(fminf(acc.x, b.x), fmaxf(acc.y, b.y));
+        }
+        if (in_lds) lds[k] = acc;
+        if (j > 0) row_level[k] = acc;             // level (0, 0) is the input itself
+    }
+    if (!in_lds) __threadfence_block();
+    __syncthreads();
+    for (int i = 1; i < li; ++i) {
+        float2 *dst = T + (size_t)(i * lj + j) * n;
+        const int rows = 1 << i;
         for (int k = threadIdx.x; k < n; k += blockDim.x) {
             const int ty = k / tw, tx = k - ty * tw;
-            const float2 a = src[k], b = src[ty * tw + min(tx + step, tw - 1)];
-            dst[k] = make_float2(fminf(a.x, b.x), fmaxf(a.y, b.y));
-        }
-    }
-    for (int i = 1; i < li; ++i) {
-        __syncthreads();
-        const int step = 1 << (i - 1);
-        for (int j = 0; j < lj; ++j) {
-            const float2 *src = level(i - 1, j);
-            float2 *dst = level(i, j);
-            for (int k = threadIdx.x; k < n; k += blockDim.x) {
-                const int ty = k / tw, tx = k - ty * tw;
-                const float2 a = src[k], b = src[min(ty + step, th - 1) * tw + tx];
-                dst[k] = make_float2(fminf(a.x, b.x), fmaxf(a.y, b.y));
+            const int last = min(ty + rows - 1, th - 1);
+            float2 acc = in_lds ? lds[k] : row_level[k];
+            for (int y = ty + 1; y <= last; ++y) {
+                const float2 b = in_lds ? lds[y * tw + tx] : (j > 0 ? row_level[y * tw + tx] : base[y * tw + tx]);
+                acc = make_float2(fminf(acc.x, b.x), fmaxf(acc.y, b.y));
             }
+            dst[k] = acc;
         }
     }
 }

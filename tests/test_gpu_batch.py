@@ -106,3 +106,56 @@ def test_object_origin_negative_zero_and_stream_order(cuda, oracle):
         got2 = capi.object_origin(out.data_ptr(), None, 480, 640, synth.TUM_K)
         want2 = oracle.object_origin((raw.astype(np.float32) * (np.float32(1.0) / np.float32(5000.0))).astype(np.float32), synth.TUM_K)
         assert np.array_equal(got2.view(np.uint32), want2.view(np.uint32)) and want2[2] == np.float32(1.5)
+
+
+@pytest.mark.parametrize("classified", [True, False])
+def test_instance_masked_object_volumes_skip_exactly(cuda, oracle, classified):
+    """The reference's call shape at its own grid size: 200^3 @ 4 mm object volumes, each fed depth x its instance mask,
+    one frame per call -- batched launch and per-volume tsdf_integrate_masked_device.  With the per-workgroup
+    classification (default) the workgroups outside an instance leave at once; results must not depend on it (variant 7
+    switches it off) and must equal the oracle bit for bit.  One frame carries +inf outside the masks: inf x 0 = NaN,
+    which DOES update a voxel (ref: src/tsdf.cu:46,49), so those tiles may claim nothing."""
+    rng = np.random.default_rng(21)
+    dims, vs = (200, 200, 200), 0.004
+    K = synth.TUM_K
+    objs = []
+    for i in range(4):
+        o = np.array([-0.4 + rng.uniform(-0.25, 0.25), -0.4 + rng.uniform(-0.2, 0.2), 0.7 + rng.uniform(0, 0.6)], np.float32)
+        c = o + 0.4
+        m = np.zeros((480, 640), np.uint8)
+        u0, u1 = K[0] * (c[0] - 0.2) / c[2] + K[2], K[0] * (c[0] + 0.2) / c[2] + K[2]
+        v0, v1 = K[4] * (c[1] - 0.2) / c[2] + K[5], K[4] * (c[1] + 0.2) / c[2] + K[5]
+        m[max(0, int(v0)):max(0, min(480, int(v1))), max(0, int(u0)):max(0, min(640, int(u1)))] = 255
+        objs.append((o, m))
+    cfgs = [capi.make_config(dims, vs, o, vol_id=i) for i, (o, _) in enumerate(objs)]
+    scene = synth.SurfScene(dims, vs, np.array([-0.4, -0.4, 0.7], np.float32))
+    frames = []
+    for k in range(3):
+        pose = scene.pose(k, 6)
+        depth = scene.depth(pose, quantize=True)
+        if k == 1:
+            depth[5:9, 600:620] = np.inf
+        frames.append((pose, depth))
+    refs = [oracle.init_grid(dims) for _ in objs]
+    with np.errstate(invalid="ignore"):
+        for pose, depth in frames:
+            for (o, m), (rt, rw), cfg in zip(objs, refs, cfgs):
+                oracle.integrate(cfg.cam_K, pose, oracle.mask_depth(depth, m), dims, o, vs, cfg.trunc_margin, rt, rw, threads=8)
+    m_dev = [cuda.from_numpy(m).cuda() for _, m in objs]
+    d_dev = [cuda.from_numpy(d).cuda() for _, d in frames]
+    with capi.Batch(cfgs) as batch:
+        batch.volumes[0].set_kernel_variant(8 if classified else 7)   # 8: classify whatever the launch size
+        for (pose, _), d in zip(frames, d_dev):
+            batch.integrate_device(d.data_ptr(), [m.data_ptr() for m in m_dev], pose)
+        batch.sync()
+        for vol, (rt, rw) in zip(batch.volumes, refs):
+            t, w = vol.download()
+            assert np.array_equal(w, rw) and np.array_equal(t.view(np.uint32), rt.view(np.uint32)), f"batch volume {vol.cfg.id}"
+    for cfg, (o, m), md, (rt, rw) in zip(cfgs, objs, m_dev, refs):
+        with capi.Volume(cfg) as vol:
+            vol.set_kernel_variant(8 if classified else 7)
+            for (pose, _), d in zip(frames, d_dev):
+                vol.integrate_masked_device(d.data_ptr(), md.data_ptr(), pose)
+            t, w = vol.download()
+        assert np.array_equal(w, rw) and np.array_equal(t.view(np.uint32), rt.view(np.uint32)), f"volume {cfg.id}"
+    assert sum(float(rw.sum()) for _, rw in refs) > 10000 and sum(1 for _, rw in refs if rw.sum() > 1000) >= 2

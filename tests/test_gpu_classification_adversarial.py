@@ -148,3 +148,38 @@ def test_non_finite_pixels_inside_claimable_tiles(cuda, oracle, dims, vs):
         frames.append((pose, depth))
     ref_t, ref_w = run_case(cuda, oracle, dims, vs, origin, None, frames)
     assert np.isfinite(ref_t).all()
+
+
+def test_large_image_tile_table_beyond_lds(cuda, oracle):
+    """A 1024 x 768 image has 64 x 48 = 3072 depth tiles: more than the sparse-table kernel keeps in LDS, so its upper
+    levels are built from memory.  Claims (free space, skipped) and bit-exactness as for the small images."""
+    h, w = 768, 1024
+    dims, vs = (256, 48, 24), 0.003
+    origin = synth.surf_volume(256, vs, 0.9)
+    K = np.array([820.0, 0, 511.3, 0, 825.0, 383.6, 0, 0, 1], np.float32)
+    cfg = capi.make_config(dims, vs, origin, K=K, im_height=h, im_width=w)
+    near, far = float(origin[2]), float(origin[2] + dims[2] * vs)
+    rng = np.random.default_rng(9)
+    frames = []
+    for k in range(6):
+        depth = np.full((h, w), far + 0.4 if k % 2 == 0 else near - 0.1, np.float32)
+        depth[rng.integers(0, h, 50), rng.integers(0, w, 50)] = rng.choice(np.array([0.0, np.nan, far - 0.02], np.float32), 50)
+        if k == 4:
+            depth[:, : w // 2] = (near + far) / 2
+        frames.append((synth.make_pose(synth.rot_z(0.02 * k), [0.002 * k, 0.0, 0.0]), depth))
+    ref_t, ref_w = oracle.init_grid(dims)
+    with np.errstate(invalid="ignore"):
+        for c2w, depth in frames:
+            oracle.integrate(K, c2w, depth, dims, origin, vs, cfg.trunc_margin, ref_t, ref_w, threads=8)
+    keep = [cuda.from_numpy(d).cuda() for _, d in frames]
+    for variant in (8, 0, 7):
+        with capi.Volume(cfg) as vol:
+            vol.set_kernel_variant(variant)
+            if variant == 8:
+                vol.shortcut_stats(True)
+            vol.integrate_frames_device([d.data_ptr() for d in keep], np.stack([p for p, _ in frames]))
+            if variant == 8:
+                per_voxel, free, skipped = vol.shortcut_stats(False)
+                assert free > 0 and skipped > 0
+            t, wgt = vol.download()
+        assert np.array_equal(wgt, ref_w) and np.array_equal(t.view(np.uint32), ref_t.view(np.uint32)), variant

@@ -1,7 +1,7 @@
 """Development probe: n object volumes of the reference's default size (200^3 @ 4 mm), one frame per call -- the
 reference's real call shape (one TSDF per object instance fed depth x its instance mask, ref: src/Engine.cpp:172-233,
 src/Object.cpp:67) -- as one batched launch and as n per-volume launches, each with and without the per-workgroup
-classification of masked frames (kernel variant 7 switches it off).
+classification of masked frames (kernel variant 0: the library's size policy; 8: always; 7: never).
 
     python tools/batch_time.py [--n 16] [--edge 200] [--masks instance|full|none]
 """
@@ -49,9 +49,10 @@ frames = args.frames
 cover = float(np.mean([m.mean() / 255.0 for m in masks]))
 vox = n * E ** 3
 print(f"{n} volumes of {E}^3, masks: {args.masks} (mean coverage {cover:.2f} of the image)")
-for cls in (True, False):
+NAMES = {0: "by policy", 8: "forced on", 7: "off      "}
+for cls in (0, 8, 7):
     with capi.Batch(cfgs) as batch:
-        batch.volumes[0].set_kernel_variant(0 if cls else 7)
+        batch.volumes[0].set_kernel_variant(cls)
         for k in range(10):
             batch.integrate_device(depth.data_ptr(), ptrs, poses[k % 8])
         batch.sync()
@@ -61,12 +62,12 @@ for cls in (True, False):
         batch.sync()
         tb = (time.perf_counter() - t0) / frames
         upd = sum(float(v.download()[1].sum()) for v in batch.volumes) / (frames + 10)
-    print(f"  batched launch, classification {'on ' if cls else 'off'}: {tb * 1e3:.3f} ms/frame ({vox / tb / 1e6:.0f} Mvox/s), "
+    print(f"  batched launch, classification {NAMES[cls]}: {tb * 1e3:.3f} ms/frame ({vox / tb / 1e6:.0f} Mvox/s), "
           f"{upd / vox:.3f} of the voxels updated per frame", flush=True)
-for cls in (True, False):
+for cls in (0, 8, 7):
     vols = [capi.Volume(c) for c in cfgs]
     for v in vols:
-        v.set_kernel_variant(0 if cls else 7)
+        v.set_kernel_variant(cls)
 
     def one(k):
         for i, v in enumerate(vols):
@@ -86,4 +87,4 @@ for cls in (True, False):
     ts = (time.perf_counter() - t0) / frames
     for v in vols:
         v.close()
-    print(f"  per-volume launches, classification {'on ' if cls else 'off'}: {ts * 1e3:.3f} ms/frame ({vox / ts / 1e6:.0f} Mvox/s)", flush=True)
+    print(f"  per-volume launches, classification {NAMES[cls]}: {ts * 1e3:.3f} ms/frame ({vox / ts / 1e6:.0f} Mvox/s)", flush=True)
