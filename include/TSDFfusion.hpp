@@ -12,8 +12,9 @@
 // The reference's C++ signature carries no camera pose although its Python side needs one
 // (ref: include/TSDFfusion.hpp:49 vs src/TSDFfusion.py.in:31).  Here: SetPose() before the
 // 2-argument Integrate (which uses the last pose set, identity at first), or the 3-argument
-// overload.  Colour is accepted and ignored (the dense-grid path fuses geometry only).
-// The voxel update is the reference's own GpuIntegrate rule (ref: src/tsdf.cu:15-60); parity
+// overload.  Colour is fused beside the distance as tsdf-fusion-python does it (per channel the
+// weighted running mean, rounded and clamped; csrc/tsdf_colour.hip.h) and SaveMesh writes it per
+// vertex.  The voxel update is the reference's own GpuIntegrate rule (ref: src/tsdf.cu:15-60); parity
 // with tsdf-fusion-python's arithmetic is unpinned because that package is absent.
 #ifndef TSDF_HIP_DROPIN_TSDFFUSION_HPP
 #define TSDF_HIP_DROPIN_TSDFFUSION_HPP
@@ -41,13 +42,13 @@ class TSDFfusion
 
 #ifdef TSDFFUSION_HAVE_OPENCV
 		/**	Integrate an RGB-D frame (ref: include/TSDFfusion.hpp:49)
-		@param imRGB colour image (ignored)
+		@param imRGB colour image, CV_8UC3 of the depth image's size, channel 0 into the low byte (may be empty)
 		@param imD depth image, CV_32F metres, 480x640 contiguous
 		*/
 		void Integrate(cv::Mat imRGB, cv::Mat imD);
 		void Integrate(cv::Mat imRGB, cv::Mat imD, cv::Mat cam2world);
 #endif
-		/** OpenCV-free forms: depth is height*width floats in metres. */
+		/** OpenCV-free forms: depth is height*width floats in metres, rgb height*width*3 bytes or NULL. */
 		void Integrate(const unsigned char *rgb, const float *depth, int height, int width);
 		void Integrate(const unsigned char *rgb, const float *depth, int height, int width,
 		               const float cam2world[16]);

@@ -327,6 +327,27 @@ int tsdf_integrate_labels_device(tsdf_volume *vol, const float *depth_dev, const
 int tsdf_download_labels(tsdf_volume *vol, uint16_t *label_host, float *fp_host, float *bp_host);
 
 /*
+ * Per-voxel colour fusion for the TSDFfusion surface.  The reference's second backend passes every RGB-D frame to the
+ * third-party tsdf-fusion-python (ref: src/TSDFfusion.py.in:43 `integrate(color_image, depth_im, cam_intr, cam_pose,
+ * obs_weight=1.)`), which fuses colour beside the distance and colours its mesh (ref: src/TSDFfusion.py.in:48-53).  That
+ * package is absent, so this restates its published rule (csrc/tsdf_colour.hip.h): every voxel a frame updates takes per
+ * 8-bit channel min(255, round((c * w_old + c_pixel) / w_new)); parity unpinned.
+ *   tsdf_colour_enable            allocate (or clear) one packed colour (0x00BBGGRR) per voxel of the slab
+ *   tsdf_integrate_colour_device  the colour pass of ONE frame, to be queued right after that frame's
+ *                                 tsdf_integrate*_device call (it reads the weights that call has written);
+ *                                 rgb_dev: im_height*im_width*3 bytes, channel 0 = R
+ *   tsdf_integrate_rgbd           both passes from host images (TSDFfusion::Integrate): copies depth and colour to
+ *                                 pinned staging, integrates, then fuses colour; the call does not wait
+ *   tsdf_download_colour          copy the packed colours out (tsdf_slab_voxels() uint32)
+ * With colour enabled tsdf_save_mesh_ply writes per-vertex red/green/blue (the nearest voxel's colour).
+ */
+int tsdf_colour_enable(tsdf_volume *vol);
+int tsdf_integrate_colour_device(tsdf_volume *vol, const float *depth_dev, const uint8_t *rgb_dev,
+                                 const float cam2world[16]);
+int tsdf_integrate_rgbd(tsdf_volume *vol, const float *depth_host, const uint8_t *rgb_host, const float cam2world[16]);
+int tsdf_download_colour(tsdf_volume *vol, uint32_t *colour_host);
+
+/*
  * Grid origin of a new object volume from its first (masked) depth frame, on the device: the per-axis
  * minimum over pixels with depth > 0 of the back-projected point, starting from 1000 -- what
  * Object::Object computes on the host before it constructs its TSDF (ref: src/Object.cpp:37-49, with the

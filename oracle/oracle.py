@@ -76,6 +76,11 @@ class Oracle:
         L.oracle_compose_labels.argtypes = [np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS"), u16p, _f32p,
                                             C.c_int, C.c_int, u16p, _f32p]
         L.oracle_max_threads.restype = C.c_int
+        u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+        u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+        L.oracle_integrate_colour.restype = C.c_int64
+        L.oracle_integrate_colour.argtypes = [_f32p, _f32p, _f32p, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _f32p, u32p]
 
     # --- grid ---------------------------------------------------------------------------
     def init_grid(self, dims, z_begin=0, z_end=None):
@@ -195,6 +200,17 @@ class Oracle:
             _f32(K).ravel(), _f32(cam2base).ravel(), _f32(depth), np.ascontiguousarray(label_im, np.uint16),
             _f32(score_im), h, w, dx, dy, z_begin, z_end, origin[0], origin[1], origin[2], voxel_size, trunc,
             max_depth, prob_thd, label, fp, bp))
+
+    # --- per-voxel colour fusion (tsdf-fusion-python's published rule, see tsdf_oracle.c) ----------
+    def integrate_colour(self, K, cam2base, depth, rgb, dims, origin, voxel_size, trunc, weight, colour,
+                         z_begin=0, z_end=None, max_depth=6.0):
+        """Colour pass of a frame whose oracle.integrate has already run (weight holds w_new).  colour: uint32 in place."""
+        dx, dy, dz = dims
+        z_end = dz if z_end is None else z_end
+        h, w = depth.shape
+        return int(self.lib.oracle_integrate_colour(
+            _f32(K).ravel(), _f32(cam2base).ravel(), _f32(depth), np.ascontiguousarray(rgb, np.uint8), h, w, dx, dy,
+            z_begin, z_end, origin[0], origin[1], origin[2], voxel_size, trunc, max_depth, weight, colour))
 
     def compose_labels(self, masks, labels, scores):
         masks = np.ascontiguousarray(masks, np.uint8)

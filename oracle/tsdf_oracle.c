@@ -525,6 +525,58 @@ void oracle_compose_labels(const uint8_t *masks, const uint16_t *labels, const f
     }
 }
 
+/* ----------------------------------------------------------------------------------
+ * Per-voxel colour fusion (the TSDFfusion surface).  The rule is tsdf-fusion-python's (the package the reference's
+ * Python glue calls, src/TSDFfusion.py.in:43; absent, version unpinned): every voxel the frame updates -- the same
+ * tests as oracle_integrate, which must have run for this frame already, so weight[] holds w_new -- takes per 8-bit
+ * channel min(255, round((c * w_old + c_pixel) / w_new)) with w_old = w_new - 1; channels packed B << 16 | G << 8 | R,
+ * rgb = 3 bytes per pixel, channel 0 = R.  Returns the number of voxels coloured.  Parity unpinned by reference output.
+ * ---------------------------------------------------------------------------------- */
+static uint32_t blend_channel(uint32_t old_c, uint32_t new_c, float w_old, float w_new)
+{
+    float v = roundf(((float)old_c * w_old + (float)new_c) / w_new);
+    v = fminf(v, 255.0f);
+    return (uint32_t)v;
+}
+
+int64_t oracle_integrate_colour(const float *cam_K, const float *cam2base, const float *depth_im, const uint8_t *rgb,
+                                int im_height, int im_width, int dim_x, int dim_y, int z_begin, int z_end,
+                                float origin_x, float origin_y, float origin_z, float voxel_size, float trunc_margin,
+                                float max_depth, const float *weight, uint32_t *colour)
+{
+    int64_t n = 0;
+    for (int gz = z_begin; gz < z_end; ++gz)
+        for (int gy = 0; gy < dim_y; ++gy)
+            for (int gx = 0; gx < dim_x; ++gx) {
+                const int64_t i = ((int64_t)(gz - z_begin) * dim_y + gy) * dim_x + gx;
+                float bx = origin_x + (float)gx * voxel_size;
+                float by = origin_y + (float)gy * voxel_size;
+                float bz = origin_z + (float)gz * voxel_size;
+                float dx = bx - cam2base[3], dy = by - cam2base[7], dz = bz - cam2base[11];
+                float cx = cam2base[0] * dx + cam2base[4] * dy + cam2base[8] * dz;
+                float cy = cam2base[1] * dx + cam2base[5] * dy + cam2base[9] * dz;
+                float cz = cam2base[2] * dx + cam2base[6] * dy + cam2base[10] * dz;
+                if (cz <= 0.0f) continue;
+                float pu = roundf(cam_K[0] * (cx / cz) + cam_K[2]);
+                float pv = roundf(cam_K[4] * (cy / cz) + cam_K[5]);
+                if (!(pu >= 0.0f && pu < (float)im_width && pv >= 0.0f && pv < (float)im_height)) continue;
+                const int pix = (int)pv * im_width + (int)pu;
+                float d = depth_im[pix];
+                if (d <= 0.0f || d > max_depth) continue;
+                float diff = d - cz;
+                if (diff <= -trunc_margin) continue;
+                const float w_new = weight[i], w_old = w_new - 1.0f;
+                const uint8_t *px = rgb + (int64_t)pix * 3;
+                const uint32_t c = colour[i];
+                const uint32_t r = blend_channel(c & 255u, px[0], w_old, w_new);
+                const uint32_t g = blend_channel((c >> 8) & 255u, px[1], w_old, w_new);
+                const uint32_t b = blend_channel((c >> 16) & 255u, px[2], w_old, w_new);
+                colour[i] = (b << 16) | (g << 8) | r;
+                ++n;
+            }
+    return n;
+}
+
 int oracle_max_threads(void)
 {
 #ifdef _OPENMP

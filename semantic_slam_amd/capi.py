@@ -26,6 +26,7 @@ ABI_SYMBOLS = [
     "tsdf_version", "tsdf_multiply_matrix", "tsdf_invert_matrix",
     "tsdf_labels_enable", "tsdf_compose_labels", "tsdf_integrate_labels_device", "tsdf_integrate_frames_labels_device",
     "tsdf_download_labels",
+    "tsdf_colour_enable", "tsdf_integrate_colour_device", "tsdf_integrate_rgbd", "tsdf_download_colour",
     "tsdf_object_origin", "tsdf_batch_create", "tsdf_batch_destroy", "tsdf_batch_size", "tsdf_batch_volume",
     "tsdf_batch_integrate_device", "tsdf_batch_sync",
     "tsdf_group_create", "tsdf_group_destroy", "tsdf_group_size", "tsdf_group_voxels", "tsdf_group_volume",
@@ -117,6 +118,10 @@ def load():
     L.tsdf_integrate_labels_device.argtypes = [vp, vp, vp, vp, vp]
     L.tsdf_download_labels.argtypes = [vp, vp, vp, vp]
     L.tsdf_integrate_frames_labels_device.argtypes = [vp, vp, vp, vp, vp, C.c_int32]
+    L.tsdf_colour_enable.argtypes = [vp]
+    L.tsdf_integrate_colour_device.argtypes = [vp, vp, vp, vp]
+    L.tsdf_integrate_rgbd.argtypes = [vp, vp, vp, vp]
+    L.tsdf_download_colour.argtypes = [vp, vp]
     L.tsdf_object_origin.argtypes = [C.c_int32, vp, vp, C.c_int32, C.c_int32, vp, vp]
     L.tsdf_batch_create.argtypes = [C.POINTER(TsdfConfig), C.c_int32, C.POINTER(vp)]
     L.tsdf_batch_destroy.argtypes = [vp]
@@ -428,6 +433,28 @@ class Volume:
         lab, fp, bp = np.empty(n, np.uint16), np.empty(n, np.float32), np.empty(n, np.float32)
         check(self.lib.tsdf_download_labels(self._h, lab.ctypes.data, fp.ctypes.data, bp.ctypes.data), "tsdf_download_labels")
         return lab, fp, bp
+
+    # -- per-voxel colour fusion ----------------------------------------------------------------
+    def colour_enable(self):
+        check(self.lib.tsdf_colour_enable(self._h), "tsdf_colour_enable")
+
+    def integrate_colour_device(self, depth_ptr, rgb_ptr, cam2world):
+        """Colour pass of the frame just integrated (queue right after integrate*_device of the same frame)."""
+        p = _f32(cam2world, 16)
+        check(self.lib.tsdf_integrate_colour_device(self._h, depth_ptr, rgb_ptr, p.ctypes.data), "tsdf_integrate_colour_device")
+
+    def integrate_rgbd(self, depth_host, rgb_host, cam2world):
+        d = _f32(depth_host, self.cfg.im_height * self.cfg.im_width)
+        c = np.ascontiguousarray(rgb_host, dtype=np.uint8).ravel()
+        if c.size != 3 * self.cfg.im_height * self.cfg.im_width:
+            raise ValueError("colour image must be height x width x 3 bytes")
+        p = _f32(cam2world, 16)
+        check(self.lib.tsdf_integrate_rgbd(self._h, d.ctypes.data, c.ctypes.data, p.ctypes.data), "tsdf_integrate_rgbd")
+
+    def download_colour(self):
+        out = np.empty(self.n_voxels, np.uint32)
+        check(self.lib.tsdf_download_colour(self._h, out.ctypes.data), "tsdf_download_colour")
+        return out
 
     # -- outputs ----------------------------------------------------------------------------
     def count_surface(self, weight_thresh=0.9):

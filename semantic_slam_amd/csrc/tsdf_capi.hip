@@ -25,6 +25,7 @@
 #include "tsdf_kernels.hip.h"
 #include "tsdf_multiframe.hip.h"
 #include "tsdf_labels.hip.h"
+#include "tsdf_colour.hip.h"
 #include "tsdf_extract.hip.h"
 
 namespace {
@@ -84,6 +85,10 @@ struct tsdf_volume {
     uint16_t *d_label;
     float *d_fp, *d_bp;
     float prob_thd;
+    // per-voxel colour (allocated by tsdf_colour_enable): packed 0x00BBGGRR; staging of the RGB frames of tsdf_integrate_rgbd
+    uint32_t *d_colour;
+    uint8_t *d_rgb[kStageSlots];
+    uint8_t *h_rgb[kStageSlots];
     // free-space summary (one word per 256-voxel row segment), see tsdf_kernels.hip.h
     uint32_t *d_flags;
     size_t n_flags;
@@ -705,15 +710,28 @@ int write_points_ply(const char *path, const float *xyz, int64_t n, const char *
     return TSDF_OK;
 }
 
-// binary .ply with vertex + face elements, three vertices per triangle
-int write_mesh_ply(const char *path, const float *tri, int64_t n, const char *who)
+// binary .ply with vertex + face elements, three vertices per triangle; rgb (may be null): 3 bytes per vertex
+int write_mesh_ply(const char *path, const float *tri, int64_t n, const char *who, const unsigned char *rgb = nullptr)
 {
     FILE *fp = std::fopen(path, "wb");
     if (!fp) return fail(TSDF_ERR_IO, "%s: cannot open %s", who, path);
     std::fprintf(fp, "ply\nformat binary_little_endian 1.0\nelement vertex %lld\n", (long long)(3 * n));
     std::fprintf(fp, "property float x\nproperty float y\nproperty float z\n");
+    if (rgb) std::fprintf(fp, "property uchar red\nproperty uchar green\nproperty uchar blue\n");
     std::fprintf(fp, "element face %lld\nproperty list uchar int vertex_indices\nend_header\n", (long long)n);
-    size_t ok = std::fwrite(tri, sizeof(float), (size_t)n * 9, fp);
+    size_t ok = 0, want = 0;
+    if (rgb) {
+        std::vector<unsigned char> rec((size_t)(n > 0 ? n : 1) * 3 * 15);
+        for (int64_t k = 0; k < 3 * n; ++k) {
+            std::memcpy(rec.data() + 15 * k, tri + 3 * k, 12);
+            std::memcpy(rec.data() + 15 * k + 12, rgb + 3 * k, 3);
+        }
+        ok = std::fwrite(rec.data(), 15, (size_t)n * 3, fp);
+        want = (size_t)n * 3;
+    } else {
+        ok = std::fwrite(tri, sizeof(float), (size_t)n * 9, fp);
+        want = (size_t)n * 9;
+    }
     std::vector<unsigned char> faces((size_t)(n > 0 ? n : 1) * 13);
     for (int64_t f = 0; f < n; ++f) {
         unsigned char *rec = faces.data() + 13 * f;
@@ -722,7 +740,7 @@ int write_mesh_ply(const char *path, const float *tri, int64_t n, const char *wh
     }
     ok += std::fwrite(faces.data(), 13, (size_t)n, fp);
     int bad = std::fclose(fp);
-    if (ok != (size_t)n * 9 + (size_t)n || bad) return fail(TSDF_ERR_IO, "%s: short write to %s", who, path);
+    if (ok != want + (size_t)n || bad) return fail(TSDF_ERR_IO, "%s: short write to %s", who, path);
     return TSDF_OK;
 }
 
@@ -862,6 +880,11 @@ int tsdf_destroy(tsdf_volume *v)
         if (v->h_frames[i]) (void)hipHostFree(v->h_frames[i]);
         if (v->d_frames[i]) (void)hipFree(v->d_frames[i]);
         if (v->frames_done[i]) (void)hipEventDestroy(v->frames_done[i]);
+    }
+    if (v->d_colour) (void)hipFree(v->d_colour);
+    for (int i = 0; i < kStageSlots; ++i) {
+        if (v->d_rgb[i]) (void)hipFree(v->d_rgb[i]);
+        if (v->h_rgb[i]) (void)hipHostFree(v->h_rgb[i]);
     }
     if (v->d_label) (void)hipFree(v->d_label);
     if (v->d_fp) (void)hipFree(v->d_fp);
@@ -1392,6 +1415,87 @@ int tsdf_compose_labels(tsdf_volume *v, const uint8_t *masks_dev, const uint16_t
 }
 
 // ---------------------------------------------------------------------------------------------
+// per-voxel colour fusion (csrc/tsdf_colour.hip.h)
+// ---------------------------------------------------------------------------------------------
+int tsdf_colour_enable(tsdf_volume *v)
+{
+    if (!v) return fail(TSDF_ERR_INVALID, "tsdf_colour_enable: NULL handle");
+    if (v->cfg.dim_x % 4 != 0) return fail(TSDF_ERR_INVALID, "tsdf_colour_enable: dim_x must be a multiple of 4");
+    int rc = bind_device(v);
+    if (rc) return rc;
+    const size_t n = (size_t)(v->n_vox > 0 ? v->n_vox : 1);
+    if (!v->d_colour) HIP_TRY(hipMalloc((void **)&v->d_colour, n * sizeof(uint32_t)));
+    HIP_TRY(hipMemsetAsync(v->d_colour, 0, n * sizeof(uint32_t), v->stream));
+    return TSDF_OK;
+}
+
+static int launch_colour(tsdf_volume *v, const float *depth_dev, const uint8_t *rgb_dev, const float *c2b)
+{
+    const int nz = v->cfg.z_end - v->cfg.z_begin;
+    if (nz == 0) return TSDF_OK;
+    tsdfk::ColourParams cp;
+    cp.g = make_params(v, depth_dev, nullptr, c2b, 4);
+    cp.rgb = rgb_dev;
+    cp.colour = v->d_colour;
+    dim3 block(64, 4, 1), grid((cp.g.xgroups + 63) / 64, (v->cfg.dim_y + 3) / 4, nz);
+    hipLaunchKernelGGL(tsdfk::integrate_colour, grid, block, 0, v->stream, cp);
+    HIP_TRY(hipGetLastError());
+    return TSDF_OK;
+}
+
+int tsdf_integrate_colour_device(tsdf_volume *v, const float *depth_dev, const uint8_t *rgb_dev, const float cam2world[16])
+{
+    if (!v || !depth_dev || !rgb_dev || !cam2world) return fail(TSDF_ERR_INVALID, "tsdf_integrate_colour_device: NULL argument");
+    if (!v->d_colour) return fail(TSDF_ERR_INVALID, "tsdf_integrate_colour_device: call tsdf_colour_enable first");
+    int rc = bind_device(v);
+    if (rc) return rc;
+    float c2b[16];
+    compose_cam2base(v, cam2world, c2b);
+    return launch_colour(v, depth_dev, rgb_dev, c2b);
+}
+
+int tsdf_integrate_rgbd(tsdf_volume *v, const float *depth_host, const uint8_t *rgb_host, const float cam2world[16])
+{
+    if (!v || !depth_host || !rgb_host || !cam2world) return fail(TSDF_ERR_INVALID, "tsdf_integrate_rgbd: NULL argument");
+    if (!v->d_colour) return fail(TSDF_ERR_INVALID, "tsdf_integrate_rgbd: call tsdf_colour_enable first");
+    int rc = bind_device(v);
+    if (rc) return rc;
+    const int s = v->stage_next;
+    v->stage_next = (s + 1) % kStageSlots;
+    if (v->stage_used[s]) HIP_TRY(hipEventSynchronize(v->stage_done[s]));
+    const size_t px = (size_t)v->cfg.im_height * v->cfg.im_width, img = px * sizeof(float);
+    if (!v->d_rgb[s]) {
+        HIP_TRY(hipMalloc((void **)&v->d_rgb[s], px * 3));
+        HIP_TRY(hipHostMalloc((void **)&v->h_rgb[s], px * 3, hipHostMallocDefault));
+    }
+    std::memcpy(v->h_stage[s], depth_host, img);   // the caller may free both images after we return
+    std::memcpy(v->h_rgb[s], rgb_host, px * 3);
+    HIP_TRY(hipMemcpyAsync(v->d_stage[s], v->h_stage[s], img, hipMemcpyHostToDevice, v->copy_stream));
+    HIP_TRY(hipMemcpyAsync(v->d_rgb[s], v->h_rgb[s], px * 3, hipMemcpyHostToDevice, v->copy_stream));
+    HIP_TRY(hipEventRecord(v->copy_done[s], v->copy_stream));
+    HIP_TRY(hipStreamWaitEvent(v->stream, v->copy_done[s], 0));
+    float c2b[16];
+    compose_cam2base(v, cam2world, c2b);
+    rc = launch_integrate(v, v->d_stage[s], nullptr, c2b);
+    if (rc == TSDF_OK) rc = launch_colour(v, v->d_stage[s], v->d_rgb[s], c2b);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(v->stage_done[s], v->stream));
+    v->stage_used[s] = true;
+    return TSDF_OK;
+}
+
+int tsdf_download_colour(tsdf_volume *v, uint32_t *colour_host)
+{
+    if (!v || !colour_host) return fail(TSDF_ERR_INVALID, "tsdf_download_colour: NULL argument");
+    if (!v->d_colour) return fail(TSDF_ERR_INVALID, "tsdf_download_colour: colour not enabled");
+    int rc = bind_device(v);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(v->stream));
+    if (v->n_vox > 0) HIP_TRY(hipMemcpy(colour_host, v->d_colour, (size_t)v->n_vox * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return TSDF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // batched per-object volumes
 // ---------------------------------------------------------------------------------------------
 int tsdf_batch_destroy(tsdf_batch *b)
@@ -1697,6 +1801,27 @@ int tsdf_save_mesh_ply(tsdf_volume *v, const char *path, float weight_thresh)
     if (n > 0) {
         rc = crossing_pass(v, nullptr, nullptr, weight_thresh, tri.data(), n, &n, true);
         if (rc) return rc;
+    }
+    if (v->d_colour) {
+        // vertex colour = colour of the nearest voxel (what the Python glue's get_mesh does with the rounded vertex indices)
+        std::vector<uint32_t> col((size_t)(v->n_vox > 0 ? v->n_vox : 1));
+        rc = tsdf_download_colour(v, col.data());
+        if (rc) return rc;
+        const tsdf_config &c = v->cfg;
+        const int nz = c.z_end - c.z_begin;
+        std::vector<unsigned char> rgb((size_t)(n > 0 ? n : 1) * 9);
+        for (int64_t k = 0; k < 3 * n; ++k) {
+            const float *p = tri.data() + 3 * k;
+            long ix = std::lround((p[0] - c.origin[0]) / c.voxel_size), iy = std::lround((p[1] - c.origin[1]) / c.voxel_size);
+            long iz = std::lround((p[2] - c.origin[2]) / c.voxel_size) - c.z_begin;
+            ix = std::min<long>(std::max<long>(ix, 0), c.dim_x - 1);
+            iy = std::min<long>(std::max<long>(iy, 0), c.dim_y - 1);
+            iz = std::min<long>(std::max<long>(iz, 0), nz - 1);
+            const uint32_t q = col[((size_t)iz * c.dim_y + (size_t)iy) * c.dim_x + (size_t)ix];
+            rgb[3 * k] = (unsigned char)(q & 255u); rgb[3 * k + 1] = (unsigned char)((q >> 8) & 255u);
+            rgb[3 * k + 2] = (unsigned char)((q >> 16) & 255u);
+        }
+        return write_mesh_ply(path, tri.data(), n, "tsdf_save_mesh_ply", rgb.data());
     }
     return write_mesh_ply(path, tri.data(), n, "tsdf_save_mesh_ply");
 }

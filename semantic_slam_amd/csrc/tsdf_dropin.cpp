@@ -139,6 +139,9 @@ void TSDFfusion::initialise()
 	cfg.origin[0] = cfg.origin[1] = cfg.origin[2] = 0.0f;
 	if (tsdf_create(&cfg, &vol_) != TSDF_OK)
 		throw std::runtime_error(std::string("Could not create the TSDF volume: ") + tsdf_last_error());
+	// colour beside the distance, as the Python glue's volume keeps it (ref: src/TSDFfusion.py.in:43)
+	if (tsdf_colour_enable(vol_) != TSDF_OK)
+		throw std::runtime_error(std::string("Could not allocate the colour volume: ") + tsdf_last_error());
 	std::memset(pose_, 0, sizeof pose_);
 	pose_[0] = pose_[5] = pose_[10] = pose_[15] = 1.0f;
 	std::cout << "Done !" << std::endl;
@@ -152,13 +155,15 @@ TSDFfusion::~TSDFfusion()
 
 void TSDFfusion::SetPose(const float cam2world[16]) { std::memcpy(pose_, cam2world, sizeof pose_); }
 
-void TSDFfusion::Integrate(const unsigned char *, const float *depth, int height, int width, const float cam2world[16])
+void TSDFfusion::Integrate(const unsigned char *rgb, const float *depth, int height, int width, const float cam2world[16])
 {
 	tsdf_config cfg;
 	tsdf_get_config(vol_, &cfg);
 	if (height != cfg.im_height || width != cfg.im_width)
 		throw std::runtime_error("TSDFfusion::Integrate: depth image must be 480x640");
-	if (tsdf_integrate(vol_, depth, cam2world) != TSDF_OK)
+	// ref: src/TSDFfusion.py.in:43 -- colour and depth fused together; without a colour image only the geometry
+	const int rc = rgb ? tsdf_integrate_rgbd(vol_, depth, rgb, cam2world) : tsdf_integrate(vol_, depth, cam2world);
+	if (rc != TSDF_OK)
 		throw std::runtime_error(std::string("TSDFfusion::Integrate: ") + tsdf_last_error());
 }
 
@@ -172,7 +177,9 @@ void TSDFfusion::Integrate(cv::Mat imRGB, cv::Mat imD)
 {
 	if (imD.type() != CV_32F || !imD.isContinuous())
 		throw std::runtime_error("TSDFfusion::Integrate: depth must be continuous CV_32F metres");
-	Integrate(imRGB.data, (const float *)imD.data, imD.rows, imD.cols, pose_);
+	if (!imRGB.empty() && (imRGB.type() != CV_8UC3 || !imRGB.isContinuous() || imRGB.rows != imD.rows || imRGB.cols != imD.cols))
+		throw std::runtime_error("TSDFfusion::Integrate: colour must be continuous CV_8UC3 of the depth image's size");
+	Integrate(imRGB.empty() ? NULL : imRGB.data, (const float *)imD.data, imD.rows, imD.cols, pose_);
 }
 
 void TSDFfusion::Integrate(cv::Mat imRGB, cv::Mat imD, cv::Mat cam2world)

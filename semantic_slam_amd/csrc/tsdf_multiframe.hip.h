@@ -107,17 +107,22 @@ __global__ __launch_bounds__(256) void depth_tile_summary(TileSummaryParams tp)
 // from 2^i rows of it.  6 x n workgroups with one barrier each instead of one workgroup per frame walking through 29
 // dependent passes (55 us per launch: a third of a one-frame launch on a 200^3 volume).  Tables of more than
 // kTileLdsEntries tiles fall back to reading level (0, j) from memory after the barrier (same values).
-constexpr int kTileLdsEntries = 2048;   // float2: 16 KiB of LDS
+constexpr int kTileLdsEntries = 2048;   // float2: 2 x 16 KiB of LDS
 
 __global__ __launch_bounds__(256) void tile_sparse_table(float2 *tables, int tw, int th)
 {
     const int lj = tile_levels(tw), li = tile_levels(th), n = tw * th;
     const int j = blockIdx.x;                      // this workgroup's x level
     float2 *T = tables + (size_t)blockIdx.y * tile_table_elems(tw, th);
-    const float2 *base = T;
     float2 *row_level = T + (size_t)j * n;         // level (0, j)
-    __shared__ float2 lds[kTileLdsEntries];
+    __shared__ float2 lds_base[kTileLdsEntries], lds_row[kTileLdsEntries];
     const bool in_lds = n <= kTileLdsEntries;
+    const float2 *base = T;
+    if (in_lds) {                                  // the frame's tiles once into LDS: every later read is an LDS read
+        for (int k = threadIdx.x; k < n; k += blockDim.x) lds_base[k] = T[k];
+        __syncthreads();
+        base = lds_base;
+    }
     const int span = 1 << j;
     for (int k = threadIdx.x; k < n; k += blockDim.x) {
         const int ty = k / tw, tx = k - ty * tw;
@@ -127,20 +132,21 @@ __global__ __launch_bounds__(256) void tile_sparse_table(float2 *tables, int tw,
             const float2 b = base[ty * tw + x];
             acc = make_float2(fminf(acc.x, b.x), fmaxf(acc.y, b.y));
         }
-        if (in_lds) lds[k] = acc;
+        if (in_lds) lds_row[k] = acc;
         if (j > 0) row_level[k] = acc;             // level (0, 0) is the input itself
     }
     if (!in_lds) __threadfence_block();
     __syncthreads();
+    const float2 *row = in_lds ? lds_row : (j > 0 ? row_level : T);
     for (int i = 1; i < li; ++i) {
         float2 *dst = T + (size_t)(i * lj + j) * n;
         const int rows = 1 << i;
         for (int k = threadIdx.x; k < n; k += blockDim.x) {
             const int ty = k / tw, tx = k - ty * tw;
             const int last = min(ty + rows - 1, th - 1);
-            float2 acc = in_lds ? lds[k] : row_level[k];
+            float2 acc = row[k];
             for (int y = ty + 1; y <= last; ++y) {
-                const float2 b = in_lds ? lds[y * tw + tx] : (j > 0 ? row_level[y * tw + tx] : base[y * tw + tx]);
+                const float2 b = row[y * tw + tx];
                 acc = make_float2(fminf(acc.x, b.x), fmaxf(acc.y, b.y));
             }
             dst[k] = acc;

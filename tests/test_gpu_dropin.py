@@ -84,28 +84,46 @@ def test_tsdffusion_native_backend(cuda, oracle, tmp_path):
     # a camera inside the [0,10]^3 room looking along +z at a sphere + wall scene placed in front of it
     scene = synth.SurfScene((200, 200, 200), 0.02, np.array([3.0, 3.0, 3.0], np.float32))
     frames = []
-    for k in range(2):
+    vv, uu = np.mgrid[0:480, 0:640]
+    for k in range(3):
         pose = synth.make_pose(synth.rot_y(0.05 * k), [5.0 + 0.1 * k, 5.0, 0.5])
-        frames.append((pose, scene.depth(pose, quantize=True)))
+        rgb = np.stack([(uu // 3 + 40 * k) % 256, (vv // 2 + 90 * k) % 256, (uu + vv + 13 * k) % 256], axis=-1).astype(np.uint8)
+        frames.append((pose, scene.depth(pose, quantize=True), rgb))
     inp = tmp_path / "frames.bin"
     with open(inp, "wb") as f:
         f.write(struct.pack("<i", len(frames)))
-        for pose, d in frames:
+        for pose, d, rgb in frames:
             f.write(pose.astype(np.float32).tobytes())
             f.write(d.astype(np.float32).tobytes())
+            f.write(rgb.tobytes())
     out = tmp_path / "cloud.ply"
     mesh = tmp_path / "mesh.ply"
     subprocess.check_call([exe, str(inp), str(out), str(mesh)], cwd=str(tmp_path))
     t, w = oracle.init_grid(dims)
-    for pose, d in frames:
-        oracle.integrate(synth.TUM_K, pose, d, dims, origin, vs, float(np.float32(vs) * np.float32(5)), t, w)
-    assert w.sum() > 10000
+    col = np.zeros(t.size, np.uint32)
+    trunc = float(np.float32(vs) * np.float32(5))
+    for pose, d, rgb in frames:
+        oracle.integrate(synth.TUM_K, pose, d, dims, origin, vs, trunc, t, w)
+        oracle.integrate_colour(synth.TUM_K, pose, d, rgb, dims, origin, vs, trunc, w, col)
+    assert w.sum() > 10000 and np.count_nonzero(col) > 10000
     oracle.save_ply(str(tmp_path / "want.ply"), t, w, dims, vs, origin)
     assert out.read_bytes() == (tmp_path / "want.ply").read_bytes()
     tri = oracle.mesh_triangles(t, w, dims[:2], 0, dims[2], vs, origin)
     raw = mesh.read_bytes()
+    head = raw[:raw.index(b"end_header\n")]
+    assert b"property uchar red" in head and b"property uchar blue" in head     # the coloured mesh of ref: TSDFfusion.py.in:48-53
     body = raw[raw.index(b"end_header\n") + len(b"end_header\n"):]
-    assert len(tri) > 1000 and body[:36 * len(tri)] == tri.tobytes()
+    n_v = 3 * len(tri)
+    rec = np.frombuffer(body[:15 * n_v], np.uint8).reshape(n_v, 15)
+    assert len(tri) > 1000 and rec[:, :12].tobytes() == tri.tobytes()
+    # vertex colour = the nearest voxel's fused colour
+    v = tri.reshape(-1, 3).astype(np.float64)
+    idx = np.clip(np.rint((v - origin) / vs).astype(np.int64), 0, np.array(dims) - 1)
+    q = col[(idx[:, 2] * dims[1] + idx[:, 1]) * dims[0] + idx[:, 0]]
+    want_rgb = np.stack([q & 255, (q >> 8) & 255, (q >> 16) & 255], axis=-1).astype(np.uint8)
+    same = np.all(rec[:, 12:] == want_rgb, axis=1)
+    assert same.mean() > 0.999, "vertex colours must be the nearest voxel's (ties at .5 may round either way)"
+    assert len(np.unique(want_rgb, axis=0)) > 50
 
 
 def test_python_mirror_of_class_tsdf(cuda, oracle, tmp_path):

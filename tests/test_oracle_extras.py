@@ -84,3 +84,33 @@ def test_mesh_rule_known_answers(oracle):
     assert len(oracle.mesh_triangles(t, w2, (2, 2), 0, 2, 1.0, np.zeros(3, f32))) == 0
     assert len(oracle.mesh_triangles(t[:4], w[:4], (2, 2), 0, 1, 1.0, np.zeros(3, f32))) == 0
     assert np.array_equal(oracle.mesh_triangles(t[:4], w[:4], (2, 2), 0, 1, 1.0, np.zeros(3, f32), halo=(t[4:], w[4:])), tri)
+
+
+def test_colour_rule_known_answers(oracle):
+    """tsdf-fusion-python's colour rule as restated in oracle_integrate_colour: per channel min(255, round((c*w_old + new)/w_new)),
+    only on voxels the frame updates, channels packed B << 16 | G << 8 | R with image channel 0 = R."""
+    dims, vs = (8, 8, 8), 0.05
+    origin = np.array([-0.2, -0.2, 1.0], np.float32)
+    K = np.array([100, 0, 32, 0, 100, 24, 0, 0, 1], np.float32)
+    pose = np.eye(4, dtype=np.float32).ravel()
+    depth = np.full((48, 64), 1.6, np.float32)            # behind the whole volume: every voxel in view is updated
+    t, w = oracle.init_grid(dims)
+    col = np.zeros(t.size, np.uint32)
+    seq = [(10, 20, 30), (11, 20, 255), (12, 21, 0), (200, 0, 7)]
+    acc = np.zeros(3)
+    for k, rgbv in enumerate(seq):
+        rgb = np.empty((48, 64, 3), np.uint8)
+        rgb[:] = rgbv
+        n_upd = oracle.integrate(K, pose, depth, dims, origin, vs, 0.25, t, w)
+        n_col = oracle.integrate_colour(K, pose, depth, rgb, dims, origin, vs, 0.25, w, col)
+        assert n_col == n_upd == t.size
+        # running mean with rounding at every step, as the package does it (round-half-away like CUDA's roundf)
+        acc = np.minimum(255, np.floor((acc * k + np.array(rgbv)) / (k + 1) + 0.5))
+        want = (int(acc[2]) << 16) | (int(acc[1]) << 8) | int(acc[0])
+        assert np.all(col == want), (k, hex(int(col[0])), hex(want))
+    # a frame that updates nothing colours nothing
+    before = col.copy()
+    none = np.zeros((48, 64), np.float32)
+    assert oracle.integrate(K, pose, none, dims, origin, vs, 0.25, t, w) == 0
+    assert oracle.integrate_colour(K, pose, none, rgb, dims, origin, vs, 0.25, w, col) == 0
+    assert np.array_equal(col, before)
