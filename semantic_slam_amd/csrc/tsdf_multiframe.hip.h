@@ -293,6 +293,10 @@ struct MultiParamsInline {
     FramePose frames[kMaxFramesPerLaunch];
     int n_frames;
     LabelState labels;   // read by the LABELS kernels only
+    // workgroup order: 0 = memory order (x blocks fastest, then y, then slices), 1 = slices fastest (grid launched as
+    // (slices, y blocks, x blocks)): consecutively dispatched workgroups then share their (x, y) footprint and with
+    // it the windows of the launch's depth frames they gather from
+    int z_fastest;
 };
 
 // FLAT: the lane's quad comes from the linear view of the slice (IntegrateParams::quads_per_slice):
@@ -645,6 +649,8 @@ __global__ __launch_bounds__(256, R == 2 ? 6 : 1) void integrate_multi_inline(Mu
     typedef const FramePose __attribute__((address_space(4))) *frames_ptr;
     frames_ptr frames = (frames_ptr)(base + offsetof(MultiParamsInline, frames));
     unsigned int free_frames = 0u, skip_frames = 0u;
+    const int wg_x = mp.z_fastest ? (int)blockIdx.z : (int)blockIdx.x, wg_y = (int)blockIdx.y;
+    const int wg_z = mp.z_fastest ? (int)blockIdx.x : (int)blockIdx.z;
     if constexpr (SHORT) {
         // Patch classification, once per workgroup: its voxels lie in one rectangle of the slice (256 x 4 voxels in
         // the row mapping, 1024 consecutive voxels in the flat one).  The first wavefront stages the frame blocks in
@@ -663,22 +669,22 @@ __global__ __launch_bounds__(256, R == 2 ? 6 : 1) void integrate_multi_inline(Mu
             for (int k = lane; k < kWords; k += 64) dst[k] = src[k];
             int xa, xb, ya, yb;
             if constexpr (FLAT) {
-                const int i0 = (int)blockIdx.x * 1024;
+                const int i0 = wg_x * 1024;
                 const int i1 = min(i0 + 1023, p.quads_per_slice * 4 - 1);
                 ya = i0 / p.dim_x;
                 yb = i1 / p.dim_x;
                 xa = ya == yb ? i0 - ya * p.dim_x : 0;
                 xb = ya == yb ? i1 - yb * p.dim_x : p.dim_x - 1;
             } else {
-                xa = (int)blockIdx.x * 256;
+                xa = wg_x * 256;
                 xb = min(xa + 255, p.dim_x - 1);
-                ya = (int)blockIdx.y * 4;
+                ya = wg_y * 4;
                 yb = min(ya + 3, p.dim_y - 1);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             int cls = 0;
-            if (lane < mp.n_frames) cls = classify_patch(p, s_frames + lane, xa, xb, ya, yb, p.z_begin + (int)blockIdx.z);
+            if (lane < mp.n_frames) cls = classify_patch(p, s_frames + lane, xa, xb, ya, yb, p.z_begin + wg_z);
             const unsigned long long fb = __ballot(cls == 1), sb = __ballot(cls == 2);
             if (lane == 0) {
                 s_bits[0] = (unsigned int)fb;
@@ -693,8 +699,8 @@ __global__ __launch_bounds__(256, R == 2 ? 6 : 1) void integrate_multi_inline(Mu
         free_frames = __builtin_amdgcn_readfirstlane(free_frames);
         skip_frames = __builtin_amdgcn_readfirstlane(skip_frames);
     }
-    multi_body<R, NT, FLAT, LABELS, MASKS, SHORT>(mp.common, (const FramePose *)frames, mp.n_frames, blockIdx.x,
-                                                  blockIdx.y, blockIdx.z, mp.labels, free_frames, skip_frames);
+    multi_body<R, NT, FLAT, LABELS, MASKS, SHORT>(mp.common, (const FramePose *)frames, mp.n_frames, wg_x, wg_y, wg_z,
+                                                  mp.labels, free_frames, skip_frames);
 }
 
 // Experiment (variant 5): XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs, so
