@@ -70,15 +70,25 @@ def test_object_callsite_sequence(cuda, oracle, tmp_path):
     assert (tmp_path / f"tsdf{vol_id}.ply").read_bytes() == (tmp_path / "want.ply").read_bytes()
 
 
-def test_tsdffusion_native_backend(cuda, oracle, tmp_path):
+@pytest.mark.parametrize("surface", ["pointers", "cv_mat"])
+def test_tsdffusion_native_backend(cuda, oracle, tmp_path, surface):
     """class TSDFfusion over the native library: the volume of the reference's Python glue
     ([0,10]^3 m at 0.02 m = 500^3, world frame, TUM intrinsics; ref: src/TSDFfusion.py.in:19-29) fed
     through the C++ class, point cloud compared with the oracle applying the reference's GpuIntegrate
-    rule to the same volume.  (The third-party package's own arithmetic is absent: parity unpinned.)"""
+    rule to the same volume.  (The third-party package's own arithmetic is absent: parity unpinned.)
+    "cv_mat": the reference's own signature Integrate(cv::Mat imRGB, cv::Mat imD) -- the overloads exist only where
+    opencv2/core.hpp does, so the harness and csrc/tsdf_dropin.cpp are compiled against tests/fake_opencv (a few
+    cv::Mat members, test scaffolding) and must produce the same files."""
     exe = str(tmp_path / "dropin_tsdffusion")
-    subprocess.check_call(["g++", "-O1", "-std=c++11", "-I", os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "tests", "dropin_tsdffusion.cpp"), "-o", exe,
-                           "-L", PKG, "-ltsdf_dropin", "-ltsdf_hip", f"-Wl,-rpath,{PKG}"])
+    if surface == "pointers":
+        subprocess.check_call(["g++", "-O1", "-std=c++11", "-I", os.path.join(ROOT, "include"),
+                               os.path.join(ROOT, "tests", "dropin_tsdffusion.cpp"), "-o", exe,
+                               "-L", PKG, "-ltsdf_dropin", "-ltsdf_hip", f"-Wl,-rpath,{PKG}"])
+    else:
+        subprocess.check_call(["g++", "-O1", "-std=c++11", "-I", os.path.join(ROOT, "tests", "fake_opencv"),
+                               "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "dropin_tsdffusion_cv.cpp"),
+                               os.path.join(PKG, "csrc", "tsdf_dropin.cpp"), "-o", exe,
+                               "-L", PKG, "-ltsdf_hip", f"-Wl,-rpath,{PKG}"])
     dims, vs = (500, 500, 500), 0.02
     origin = np.zeros(3, np.float32)
     # a camera inside the [0,10]^3 room looking along +z at a sphere + wall scene placed in front of it
