@@ -406,7 +406,7 @@ def main():
     kernel_ms = kernel_ms_total / launches
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
     if fpl == 1:
-        kname = ("tsdfk::integrate_tile<2, true, true, false, true, false, true, false>" if cfg.dim_x % 256 == 0 else
+        kname = ("tsdfk::integrate_tile<2, true, true, false, true, false, true, false, false>" if cfg.dim_x % 256 == 0 else
                  "tsdfk::integrate_multi_single<true, true>") if variant in (0, 3) else f"variant {variant}"
         ksub = "integrate_tile<" if cfg.dim_x % 256 == 0 else "integrate_multi_single<"
     else:
