@@ -180,6 +180,20 @@ def cpu_baseline(args, W, cam_K, trunc):
                      f"[{zb},{zb + nz}) of the {dims[0]}x{dims[1]}x{dims[2]} grid, {el:.1f} s"}
     if W.full_coverage:
         assert n_upd == frames * nz * per_slice, "full-coverage workload must update every voxel (N_upd == N)"
+    # the same at one thread (BASELINE.md section 4 asks for both), on an 8-slice slab, a few seconds
+    n1 = min(Dz, 8)
+    t1, w1 = orc.init_grid(dims, zb, zb + n1)
+    orc.integrate(cam_K, c2b[0], depth(0), dims, origin, vs, trunc, t1, w1, z_begin=zb, z_end=zb + n1, threads=1)
+    f1, t0 = 0, time.perf_counter()
+    while True:
+        i = (f1 + 1) % W.n_pose
+        orc.integrate(cam_K, c2b[i], depth(i), dims, origin, vs, trunc, t1, w1, z_begin=zb, z_end=zb + n1, threads=1)
+        f1 += 1
+        el1 = time.perf_counter() - t0
+        if el1 > 3.0 or f1 >= 50:
+            break
+    out["one_thread"] = {"value": round(n1 * per_slice * f1 / el1 / 1e6, 1), "unit": "Mvoxels/s", "cores": 1,
+                         "sample": f"{f1} frames into an {n1}-slice slab, {el1:.1f} s"}
     ref = None
     if Ref.available() and max(dims) <= 1024:
         # the reference body has no slab form: give it a grid that IS the slab (origin shifted in z on the host;

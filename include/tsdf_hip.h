@@ -285,6 +285,15 @@ int tsdf_selftest_fastdiv(int32_t device, uint64_t seed, uint64_t n_samples, flo
                           uint64_t *mismatches, float first_bad[4]);
 
 /*
+ * Device self-test of the truncated distance's division diff / trunc through the shared refined reciprocal (fused
+ * kernels, csrc/tsdf_kernels.hip.h: fast_div_r) against the compiler's IEEE division on n_samples operand pairs drawn
+ * from the domain the kernel admits: divisor in [2^-20, 2^20], numerator 0, NaN or of magnitude in [2^-81, 2^60].
+ * Every quotient must be bit-identical.  *mismatches must come back 0; first_bad = {n, d, got, want} otherwise.
+ */
+int tsdf_selftest_fastdiv_band(int32_t device, uint64_t seed, uint64_t n_samples, uint64_t *mismatches,
+                               float first_bad[4]);
+
+/*
  * Exhaustive device self-test of the kernel's one-instruction pixel rounding (v_cvt_rpi_i32_f32)
  * against roundf for every fp32 value in (-0.5, 2^24].  *mismatches must come back 0;
  * first_bad = {u, got, want, 0} otherwise.

@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "tsdf_sync", "tsdf_download", "tsdf_copy_slices", "tsdf_upload", "tsdf_refresh_summary", "tsdf_device_ptrs", "tsdf_slab_voxels", "tsdf_frames_per_launch", "tsdf_shortcut_stats", "tsdf_classification_info",
     "tsdf_get_config", "tsdf_last_cam2base", "tsdf_set_stream", "tsdf_get_stream",
     "tsdf_count_surface", "tsdf_extract_surface", "tsdf_extract_crossings", "tsdf_extract_mesh", "tsdf_save_mesh_ply", "tsdf_save_ply", "tsdf_save_bin", "tsdf_load_bin", "tsdf_save_state", "tsdf_load_state",
-    "tsdf_integrate_sequence_timed", "tsdf_integrate_frames_timed", "tsdf_probe_stream", "tsdf_selftest_fastdiv", "tsdf_selftest_round", "tsdf_set_kernel_variant", "tsdf_last_error",
+    "tsdf_integrate_sequence_timed", "tsdf_integrate_frames_timed", "tsdf_probe_stream", "tsdf_selftest_fastdiv", "tsdf_selftest_fastdiv_band", "tsdf_selftest_round", "tsdf_set_kernel_variant", "tsdf_last_error",
     "tsdf_version", "tsdf_multiply_matrix", "tsdf_invert_matrix",
     "tsdf_labels_enable", "tsdf_compose_labels", "tsdf_integrate_labels_device", "tsdf_integrate_frames_labels_device",
     "tsdf_download_labels",
@@ -106,6 +106,7 @@ def load():
     L.tsdf_integrate_frames_timed.argtypes = [vp, vp, vp, vp, C.c_int32, f32p]
     L.tsdf_probe_stream.argtypes = [vp, C.c_int32, C.c_int32, f32p]
     L.tsdf_selftest_fastdiv.argtypes = [C.c_int32, C.c_uint64, C.c_uint64, C.c_float, C.c_float, C.POINTER(C.c_uint64), f32p]
+    L.tsdf_selftest_fastdiv_band.argtypes = [C.c_int32, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), f32p]
     L.tsdf_selftest_round.argtypes = [C.c_int32, C.POINTER(C.c_uint64), f32p]
     L.tsdf_set_kernel_variant.argtypes = [vp, C.c_int32]
     L.tsdf_last_error.restype = C.c_char_p
@@ -208,6 +209,14 @@ def selftest_fastdiv(n_samples, seed=1, device=0, fx=535.4, cx=320.1):
     cnt = C.c_uint64()
     bad = (C.c_float * 4)()
     check(load().tsdf_selftest_fastdiv(device, seed, n_samples, fx, cx, C.byref(cnt), bad), "tsdf_selftest_fastdiv")
+    return cnt.value, list(bad)
+
+
+def selftest_fastdiv_band(n_samples, seed=1, device=0):
+    """Returns (mismatches, first_bad[4]) of the device self-test of diff / trunc through the shared reciprocal."""
+    cnt = C.c_uint64()
+    bad = (C.c_float * 4)()
+    check(load().tsdf_selftest_fastdiv_band(device, seed, n_samples, C.byref(cnt), bad), "tsdf_selftest_fastdiv_band")
     return cnt.value, list(bad)
 
 

@@ -197,6 +197,9 @@ tsdfk::IntegrateParams make_params(const tsdf_volume *v, const float *depth_dev,
              (int64_t)c.im_width * c.im_height <= (1 << 24) &&   // pixel index exact in fp32
              c.im_width < (1 << 24) && c.im_height < (1 << 24);   // and its factors fit the 24-bit multiply
         p.fast_ok = ok ? 1 : 0;
+        // diff / trunc through the shared reciprocal (tsdf_kernels.hip.h, fast_div_r): divisor and numerator ranges
+        p.trunc_fast = (ok && c.trunc_margin >= 9.5367431640625e-07f && c.trunc_margin <= 1048576.0f &&
+                        c.max_depth <= 5.7e17f) ? 1 : 0;   // 2^-20 .. 2^20; max_depth <= 2^59 (false for NaN)
         // Patch classification (tsdf_multiframe.hip.h, classify_patch).  E_k bounds how far a voxel's d_k = (o_k +
         // i*vs) - t_k, as rounded on the per-voxel path, lies from the affine function of the index (two roundings at
         // the magnitude of the coordinate, one at that of the difference); eps bounds the error of a camera-frame
@@ -1229,6 +1232,29 @@ int tsdf_selftest_fastdiv(int32_t device, uint64_t seed, uint64_t n_samples, flo
     (void)hipFree(d_cnt);
     (void)hipFree(d_bad);
     if (e != hipSuccess) return fail(TSDF_ERR_HIP, "tsdf_selftest_fastdiv: %s", hipGetErrorString(e));
+    *mismatches = cnt;
+    return TSDF_OK;
+}
+
+int tsdf_selftest_fastdiv_band(int32_t device, uint64_t seed, uint64_t n_samples, uint64_t *mismatches, float first_bad[4])
+{
+    if (!mismatches || !first_bad) return fail(TSDF_ERR_INVALID, "tsdf_selftest_fastdiv_band: NULL argument");
+    HIP_TRY(hipSetDevice(device));
+    unsigned long long *d_cnt = nullptr;
+    float *d_bad = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_cnt, sizeof *d_cnt));
+    HIP_TRY(hipMalloc((void **)&d_bad, 4 * sizeof(float)));
+    HIP_TRY(hipMemset(d_cnt, 0, sizeof *d_cnt));
+    HIP_TRY(hipMemset(d_bad, 0, 4 * sizeof(float)));
+    hipLaunchKernelGGL(tsdfk::selftest_fastdiv_band, dim3(256 * 8), dim3(256), 0, 0, seed, n_samples, d_cnt, d_bad);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    unsigned long long cnt = 0;
+    if (e == hipSuccess) e = hipMemcpy(&cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(first_bad, d_bad, 4 * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d_cnt);
+    (void)hipFree(d_bad);
+    if (e != hipSuccess) return fail(TSDF_ERR_HIP, "tsdf_selftest_fastdiv_band: %s", hipGetErrorString(e));
     *mismatches = cnt;
     return TSDF_OK;
 }

@@ -54,6 +54,9 @@ struct IntegrateParams {
     int quads_per_row, quads_per_slice, chunks_per_slice;
     // host-proved magnitude bounds that make the shared-reciprocal projection exact (see fast_div2)
     int fast_ok;
+    // 2^-20 <= trunc <= 2^20 and max_depth <= 2^59: diff / trunc may go through the shared refined reciprocal
+    // (fast_div_r) on wavefronts that took the fast projection path (see there)
+    int trunc_fast;
     // |camera z| below which a lane's patch counts as "near the camera plane": far above the rounding
     // error of cz over this slab (host: 1e-5 x the bound on |cz|), far above TSDF_FAST_D_MIN
     float cz_margin;
@@ -229,11 +232,36 @@ __global__ __launch_bounds__(256) void integrate_rows(IntegrateParams p)
 // ------------------------------------------------------------------------------------------
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ v2f fast_div2(v2f n, float d)
+// The refined reciprocal of the sequence above (r1), for a divisor that many quotients share.
+__device__ __forceinline__ float refined_rcp(float d)
 {
     const float r0 = __builtin_amdgcn_rcpf(d);
     const float e0 = __builtin_fmaf(-d, r0, 1.0f);
-    const float r1 = __builtin_fmaf(e0, r0, r0);
+    return __builtin_fmaf(e0, r0, r0);
+}
+
+// n / d from d's refined reciprocal: the five instructions in the middle of the compiler's expansion.  Used for the
+// truncated distance diff / trunc (ref: src/tsdf.cu:53), whose divisor is a launch constant: 5 instructions per voxel
+// instead of 11, r1 computed once per kernel.  Bit-identical to `/` when div_scale is the identity, div_fixup passes
+// the quotient through and no intermediate is denormal: 2^-20 <= d <= 2^20 (host: IntegrateParams::trunc_fast) and
+// n = 0 or 2^-81 <= |n| <= 2^60 -- which holds for n = depth - cz on a wavefront that took the fast projection path:
+// cz > cz_margin >= 2^-57 there, depth <= max_depth <= 2^59, |cz| <= 2^59 (fast_ok), and a non-zero difference of two
+// floats one of which is at least 2^-57 is at least 2^-81 (Sterbenz: an exact multiple of the smaller operand's ulp
+// when they are within a factor 2, at least half the larger one otherwise).  A NaN numerator (NaN depth passes the
+// reference's tests) gives NaN either way, and fmin(1, NaN) = 1.  tsdf_selftest_fastdiv_band compares it with the
+// compiler's division over exactly this domain on the device.
+__device__ __forceinline__ float fast_div_r(float n, float d, float r1)
+{
+    const float q0 = n * r1;
+    const float e1 = __builtin_fmaf(-d, q0, n);
+    const float q1 = __builtin_fmaf(e1, r1, q0);
+    const float e2 = __builtin_fmaf(-d, q1, n);
+    return __builtin_fmaf(e2, r1, q1);
+}
+
+__device__ __forceinline__ v2f fast_div2(v2f n, float d)
+{
+    const float r1 = refined_rcp(d);
     const v2f R = {r1, r1}, D = {d, d};
     const v2f q0 = n * R;
     const v2f e1 = __builtin_elementwise_fma(-D, q0, n);
@@ -687,6 +715,38 @@ __global__ __launch_bounds__(256) void selftest_fastdiv(uint64_t seed, uint64_t 
                 first_bad[0] = bad0 ? n0 : n1; first_bad[1] = d; first_bad[2] = bad0 ? q.x : q.y;
                 first_bad[3] = bad0 ? r0 : r1;
             }
+        }
+    }
+}
+
+// Device self-test of fast_div_r over the domain the truncated distance uses it on: divisors in [2^-20, 2^20],
+// numerators 0 or of magnitude in [2^-81, 2^60] (either sign, structured and random mantissas), NaN numerators.
+// Every quotient must be bit-identical to the compiler's IEEE division (NaN: both NaN).
+__global__ __launch_bounds__(256) void selftest_fastdiv_band(uint64_t seed, uint64_t n_samples, unsigned long long *mismatch,
+                                                             float *first_bad)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_samples; i += stride) {
+        const uint32_t h0 = hash32(seed + 3 * i), h1 = hash32(seed + 3 * i + 1), h2 = hash32(seed + 3 * i + 2);
+        const uint32_t mode = h2 & 7u;
+        uint32_t dm = h0 & 0x7fffffu;
+        if (mode == 1) dm = 0x7fffffu; else if (mode == 2) dm = 0u; else if (mode == 3) dm &= 0x7u;
+        const uint32_t de = 127u - 20u + (h0 >> 23) % 41u;                      // 2^-20 .. 2^20
+        const float d = __uint_as_float((de << 23) | dm);
+        uint32_t ne = 127u - 81u + (h1 >> 23) % 142u;                           // 2^-81 .. 2^60
+        if (mode >= 6) ne = de - 2u + (h1 >> 23) % 5u;                          // quotients around 1 (the clamp's edge)
+        if (ne > 127u + 60u) ne = 127u + 60u;
+        uint32_t nm = h1 & 0x7fffffu;
+        if (mode == 4) nm = 0x7fffffu; else if (mode == 5) nm = dm;
+        if (ne == 127u + 60u) nm = 0u;                                          // |n| <= 2^60
+        float n = __uint_as_float((((h2 >> 3) & 1u) << 31) | (ne << 23) | nm);
+        if (((h2 >> 5) & 63u) == 0u) n = 0.0f;
+        if (((h2 >> 5) & 63u) == 1u) n = __uint_as_float(0x7fc00000u | (h2 >> 12));   // NaN
+        const float q = fast_div_r(n, d, refined_rcp(d));
+        const float r = n / d;
+        const bool same = __float_as_uint(q) == __float_as_uint(r) || (q != q && r != r);
+        if (!same) {
+            if (atomicAdd(mismatch, 1ull) == 0ull) { first_bad[0] = n; first_bad[1] = d; first_bad[2] = q; first_bad[3] = r; }
         }
     }
 }

@@ -360,6 +360,8 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
     for (int r = 0; r < R; ++r) byv[r] = p.oy + (float)(gy0 + r) * p.vs;
     const float bz = p.oz + (float)gz * p.vs;
     const v2f F = {p.fx, p.fy}, C = {p.cx, p.cy};
+    const float trunc_r1 = refined_rcp(p.trunc);   // for fast_div_r(diff, trunc): once per kernel
+    bool fast_frame = false;                       // wave-uniform: the current frame took the fast projection path
 
     // What a frame does to the lane's voxels once upd / diff are known (ref: src/tsdf.cu:53-57): the quads are brought in
     // on first touch and updated in registers.  Shared by the per-voxel path and the classified free-space path.
@@ -378,10 +380,17 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
         }
         float dist[R][4];
         if (__ballot(band) != 0ull) {
+            if (fast_frame && p.trunc_fast != 0) {   // the same quotient from the shared refined reciprocal (fast_div_r)
 #pragma unroll
-            for (int r = 0; r < R; ++r)
+                for (int r = 0; r < R; ++r)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) dist[r][j] = fminf(1.0f, diff[r][j] / p.trunc);  // ref: :53
+                    for (int j = 0; j < 4; ++j) dist[r][j] = fminf(1.0f, fast_div_r(diff[r][j], p.trunc, trunc_r1));
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) dist[r][j] = fminf(1.0f, diff[r][j] / p.trunc);  // ref: :53
+            }
         } else {
 #pragma unroll
             for (int r = 0; r < R; ++r)
@@ -508,7 +517,8 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
             all_behind &= (pcz[R - 1][0] < -q.cz_margin) & (pcz[R - 1][3] < -q.cz_margin);
         }
         const bool unsafe = !(all_front | all_behind);
-        if (q.fast_ok != 0 && __ballot(unsafe) == 0ull) {
+        fast_frame = q.fast_ok != 0 && __ballot(unsafe) == 0ull;
+        if (fast_frame) {
             const bool front = all_front;   // the sign of cz over the whole patch (corner test)
 #pragma unroll
             for (int r = 0; r < R; ++r) {

@@ -27,3 +27,12 @@ def test_one_instruction_rounding_equals_roundf_everywhere(cuda):
     """v_cvt_rpi_i32_f32 == (int)roundf for EVERY fp32 value in (-0.5, 2^24] (exhaustive, ~2.3e9 values)."""
     bad, first = capi.selftest_round()
     assert bad == 0, f"{bad} mismatches, first: u={first[0]!r} got={first[1]!r} want={first[2]!r}"
+
+
+@pytest.mark.parametrize("seed", [3, 0xC2B2AE3D27D4EB4F, 20261005])
+def test_truncated_distance_division_is_ieee_exact(cuda, seed):
+    """diff / trunc through the launch-wide refined reciprocal (fast_div_r, fused kernels): bit-identical to `/` over the
+    whole admitted domain -- divisor in [2^-20, 2^20], numerator 0, NaN or of magnitude in [2^-81, 2^60] -- on 2^30
+    operand pairs per seed (quotients around the clamp at 1, structured mantissas, both signs)."""
+    bad, first = capi.selftest_fastdiv_band(1 << 30, seed=seed)
+    assert bad == 0, f"{bad} mismatches, first: n={first[0]!r} d={first[1]!r} got={first[2]!r} want={first[3]!r}"
