@@ -329,6 +329,8 @@ int classify_single(tsdf_volume *v, tsdfk::IntegrateParams &p, int nbx, int nby,
 //   7        as 0 but never with the per-workgroup patch classification (the per-voxel kernel alone)
 //   8        as 0 but always with it (0 decides per launch from the previous launch's claims)
 //   9        as 0 with the workgroups of a fused launch dispatched in memory order instead of slices-fastest (A/B)
+//   11       as 8 (always classified) with round 1's shape: 256 x 1 rows per wavefront, classified per workgroup (A/B
+//            of the brick mapping: 64 x 4 voxels per wavefront, classified per wavefront, the default when classifying)
 //   1        scalar kernel integrate_rows<1> (any dim_x)
 //   2        first version integrate_rows<4> (one row per wavefront, no elision)
 //   16 + c   experiments: c = (rsel << 2) | (elide << 1) | nt, R = 1, 2, 4 for rsel = 0, 1, 2
@@ -383,7 +385,7 @@ int launch_integrate(tsdf_volume *v, const float *depth_dev, const uint8_t *mask
     if (nz == 0) return TSDF_OK;  // empty slab: nothing to do
     std::memcpy(v->last_cam2base, c2b, sizeof v->last_cam2base);
     int variant = v->variant;
-    if (variant == 0 || (variant >= 3 && variant <= 9)) variant = kDefaultTile;
+    if (variant == 0 || (variant >= 3 && variant <= 11)) variant = kDefaultTile;
     if (c.dim_x % 4 != 0) variant = 1;  // rows are not 16-byte aligned: scalar kernel
     if (v->flat && variant != 1 && variant != 2) {
         // rows that are not a multiple of 256 voxels: the flat mapping (every lane busy, summary kept)
@@ -565,7 +567,7 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
                 }
             }
             bool classify = tiles_fit(mi.common) && v->variant != 7;
-            if (classify && v->variant != 8)
+            if (classify && v->variant != 8 && v->variant != 11)
                 classify = !v->claims_known || v->claim_fraction >= 0.10 || v->launches_unclassified >= 7;
             v->launches_unclassified = classify ? 0 : v->launches_unclassified + 1;
             const bool count_claims = classify && !v->claims_pending;
@@ -589,6 +591,8 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
             }
             if (v->flat && any_mask && classify)
                 hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, true, false, true, true>), grid_flat, block, 0, v->stream, mi);
+            else if (!v->flat && any_mask && classify && v->variant != 11)
+                hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, false, true, true, true>), grid_rows, block, 0, v->stream, mi);
             else if (!v->flat && any_mask && classify)
                 hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, false, true, true>), grid_rows, block, 0, v->stream, mi);
             else if (v->flat && any_mask)
@@ -599,13 +603,16 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
                 hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, true, false, false>), grid_flat, block, 0, v->stream, mi);
             else if (any_mask)
                 hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, false, true>), grid_rows, block, 0, v->stream, mi);
-            else if (classify)
+            else if (classify && v->variant != 11)   // bricks: 64 x 4 voxels per wavefront, classified per wavefront
+                hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, false, false, true, true>), grid_rows, block, 0, v->stream, mi);
+            else if (classify)                       // variant 11: rows, classified per workgroup (round 1's shape; A/B)
                 hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, false, false, true>), grid_rows, block, 0, v->stream, mi);
             else
                 hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, false, false>), grid_rows, block, 0, v->stream, mi);
             if (count_claims) {
                 const dim3 &g = v->flat ? grid_flat : grid_rows;
-                v->claims_total = (double)g.x * g.y * g.z * n;
+                // claims are counted per workgroup-frame, with bricks per wavefront-frame (four per workgroup)
+                v->claims_total = (double)g.x * g.y * g.z * n * ((!v->flat && v->variant != 11) ? 4.0 : 1.0);
                 HIP_TRY(hipMemcpyAsync(v->h_claims, v->d_claims, sizeof(unsigned long long), hipMemcpyDeviceToHost, v->stream));
                 HIP_TRY(hipEventRecord(v->claims_done, v->stream));
                 v->claims_pending = true;
@@ -661,7 +668,7 @@ int frames_per_launch(const tsdf_volume *)
 int integrate_frames(tsdf_volume *v, const float *const *depth_dev, const uint8_t *const *masks_dev,
                      const float *cam2world, int n_frames)
 {
-    const bool fuse = (v->variant == 0 || (v->variant >= 4 && v->variant <= 9)) && v->cfg.dim_x % 4 == 0;
+    const bool fuse = (v->variant == 0 || (v->variant >= 4 && v->variant <= 11)) && v->cfg.dim_x % 4 == 0;
     int rc = TSDF_OK;
     for (int k = 0; k < n_frames && rc == TSDF_OK;) {
         const int n = fuse ? std::min(frames_per_launch(v), n_frames - k) : 1;
@@ -1166,7 +1173,7 @@ int tsdf_classification_info(tsdf_volume *v, double info_out[2])
 int32_t tsdf_frames_per_launch(const tsdf_volume *v)
 {
     if (!v) return 0;
-    const bool fuse = (v->variant == 0 || (v->variant >= 4 && v->variant <= 9)) && v->cfg.dim_x % 4 == 0;
+    const bool fuse = (v->variant == 0 || (v->variant >= 4 && v->variant <= 11)) && v->cfg.dim_x % 4 == 0;
     return fuse ? frames_per_launch(v) : 1;
 }
 
@@ -1206,7 +1213,7 @@ int tsdf_set_kernel_variant(tsdf_volume *v, int32_t variant)
     if (!v) return fail(TSDF_ERR_INVALID, "tsdf_set_kernel_variant: NULL handle");
     const int c = (variant - 32) & 15;
     const bool sum_ok = (variant >= 32 && variant < 112 && c < 12 && ((c >> 1) & 1)) || variant == 115 || variant == 119;
-    if (!(variant >= 0 && variant <= 9) && !(variant >= 16 && variant < 28) && !sum_ok)
+    if (!(variant >= 0 && variant <= 11) && !(variant >= 16 && variant < 28) && !sum_ok)
         return fail(TSDF_ERR_INVALID, "tsdf_set_kernel_variant: unknown variant %d", variant);
     v->variant = variant;
     return TSDF_OK;

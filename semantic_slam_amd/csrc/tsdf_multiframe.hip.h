@@ -310,7 +310,15 @@ struct MultiParamsInline {
 // no mask bytes, defaults or null tests (2 of 44 VALU instructions per voxel-frame).
 // SHORT: the frames of the launch that come with depth tile tables are classified per wavefront in the prologue, one
 // lane per frame (classify_patch): all voxels updated with dist = 1, or none updated, without projecting any of them.
-template <int R, bool NT, bool FLAT, bool LABELS = false, bool MASKS = true, bool SHORT = false>
+// BRICK (row mapping only): the workgroup's 256 x 4 voxels are dealt to its wavefronts as four 64(x) x 4(y) bricks instead
+// of four 256 x 1 rows -- lane l of wavefront w owns the quad (w * 16 + (l & 15)) of row (l >> 4).  A wave-instruction
+// then touches four 256-byte row pieces instead of one 1-KiB piece (the fused launches are bound by instruction issue,
+// not by HBM), and the wavefront's voxels project onto a compact pixel box, so a depth tile table can decide far more
+// wavefront-frames without projecting a voxel: on S-surf an ideal classifier claims 38 % of the 256 x 1 rows but 77 % of
+// the 64 x 4 bricks (a row crosses both image borders and every silhouette on its way).  The free-space summary keeps its
+// layout (one word per 256-voxel row segment, now shared by the four wavefronts of a workgroup): a set bit was true for
+// the whole segment at launch start, each wavefront only changes its own voxels, and clearing is idempotent.
+template <int R, bool NT, bool FLAT, bool LABELS = false, bool MASKS = true, bool SHORT = false, bool BRICK = false>
 __device__ __forceinline__ void multi_body(const IntegrateParams &p, const FramePose *__restrict__ frames,
                                            const int n_frames, const int b0, const int b1, const int lz,
                                            const LabelState ls = LabelState(), const unsigned int free_frames = 0u,
@@ -319,9 +327,16 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
     static_assert(!SHORT || R == 1, "patch classification is written for one row per lane");
     static_assert(!LABELS || R == 1, "label fusion rides on the one-row kernel");
     static_assert(!FLAT || R == 1, "the flat mapping handles one quad per lane");
+    static_assert(!BRICK || (R == 1 && !FLAT), "bricks re-deal the row mapping's workgroup");
     int xg, gy0;
     size_t row0, flag0;
-    if constexpr (FLAT) {
+    if constexpr (BRICK) {
+        xg = b0 * 64 + (int)threadIdx.y * 16 + ((int)threadIdx.x & 15);
+        gy0 = b1 * 4 + ((int)threadIdx.x >> 4);
+        if (xg >= p.xgroups || gy0 >= p.dim_y) return;
+        row0 = ((size_t)lz * p.dim_y + gy0) * (size_t)p.dim_x + (size_t)xg * 4;
+        flag0 = ((size_t)lz * p.dim_y + gy0) * (size_t)p.nseg + b0;
+    } else if constexpr (FLAT) {
         const int chunk = b0 * 4 + threadIdx.y;
         const int q = chunk * 64 + threadIdx.x;
         if (q >= p.quads_per_slice) return;
@@ -340,7 +355,7 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
 
     // ---- voxel state held in registers across the frames ----------------------------------------
     uint32_t fl[R];
-    bool ones[R];            // wave-uniform: every TSDF value of the row segment is (still) exactly 1
+    bool ones[R];            // every TSDF value of the lane's row segment is (still) exactly 1 (wave-uniform unless BRICK)
     float4 t4[R], w4[R];
     bool touched[R], tchanged[R];
 #pragma unroll
@@ -401,8 +416,10 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
         // ---- update in registers (ref: src/tsdf.cu:54-57) ----------------------------------------------
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            if (ones[r] && (fl[r] & 2u) && __ballot(bandr[r]) == 0ull) {
-                // free space (see integrate_tile): the TSDF row stays 1, only the weights move
+            if (__ballot(!(ones[r] && (fl[r] & 2u)) || bandr[r]) == 0ull) {
+                // free space (see integrate_tile) for every lane of the wavefront: the TSDF rows stay 1, only the
+                // weights move.  (A lane whose row is all ones but whose neighbours' are not takes the general path
+                // below on the constant 1 that stands in for its values: the same bits.)
                 if (upd[r][0]) w4[r].x += 1.0f;
                 if (upd[r][1]) w4[r].y += 1.0f;
                 if (upd[r][2]) w4[r].z += 1.0f;
@@ -439,7 +456,11 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
             t4[r] = make_float4(tv[0], tv[1], tv[2], tv[3]);
             w4[r] = make_float4(wv[0], wv[1], wv[2], wv[3]);
             tchanged[r] |= changed;
-            if (__ballot(notone) != 0ull) ones[r] = false;   // for every lane of the wavefront
+            {   // a value != 1 appeared in the row segment: for every lane of the wavefront that shares the row
+                const unsigned long long nb = __ballot(notone);
+                if constexpr (BRICK) { if ((nb >> (((unsigned)threadIdx.x >> 4) * 16u)) & 0xffffull) ones[r] = false; }
+                else { if (nb != 0ull) ones[r] = false; }
+            }
         }
     };
 
@@ -453,7 +474,7 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
             if (skip) continue;
             if (all_free) {
                 // every voxel of the wavefront: valid pixel, diff >= trunc (dist = 1), none in the band
-                if (touched[0] && ones[0] && (fl[0] & 2u)) {   // steady state of a free-space row: only the weights move
+                if (__ballot(!(touched[0] && ones[0] && (fl[0] & 2u))) == 0ull) {   // steady state of free-space rows: only the weights move
                     w4[0].x += 1.0f; w4[0].y += 1.0f; w4[0].z += 1.0f; w4[0].w += 1.0f;
                     continue;
                 }
@@ -640,7 +661,14 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
             if (store_t) vol_store<NT>(p.tsdf + row0 + (size_t)r * p.dim_x, t4[r]);
             vol_store<NT>(p.weight + row0 + (size_t)r * p.dim_x, w4[r]);
         }
-        if ((fl[r] & 1u) && !ones[r]) p.flags[flag0 + (size_t)r * p.nseg] = fl[r] & 2u;
+        if ((fl[r] & 1u) && !ones[r]) {
+            if constexpr (BRICK) {   // the word's index again from the lane's row (not kept live across the frame loop)
+                const int gy = b1 * 4 + ((int)threadIdx.x >> 4);
+                p.flags[((size_t)lz * p.dim_y + gy) * (size_t)p.nseg + b0] = fl[r] & 2u;
+            } else {
+                p.flags[flag0 + (size_t)r * p.nseg] = fl[r] & 2u;
+            }
+        }
     }
 }
 
@@ -650,9 +678,13 @@ __global__ __launch_bounds__(256, R == 2 ? 6 : 1) void integrate_multi(MultiPara
     multi_body<R, NT, FLAT>(mp.common, mp.frames, mp.n_frames, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
-template <int R, bool NT, bool FLAT, bool LABELS = false, bool MASKS = true, bool SHORT = false>
-__global__ __launch_bounds__(256, R == 2 ? 6 : 1) void integrate_multi_inline(MultiParamsInline mp)
+#ifndef TSDF_BRICK_WAVES
+#define TSDF_BRICK_WAVES 8   /* waves per SIMD asked of the brick instantiation (A/B builds override it) */
+#endif
+template <int R, bool NT, bool FLAT, bool LABELS = false, bool MASKS = true, bool SHORT = false, bool BRICK = false>
+__global__ __launch_bounds__(256, R == 2 ? 6 : (BRICK ? TSDF_BRICK_WAVES : 1)) void integrate_multi_inline(MultiParamsInline mp)
 {
+    static_assert(!BRICK || SHORT, "the brick mapping exists for the classification's sake");
     // the single by-value parameter starts the kernarg segment (offset 0)
     typedef const char __attribute__((address_space(4))) *kernarg_ptr;
     kernarg_ptr base = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -662,55 +694,81 @@ __global__ __launch_bounds__(256, R == 2 ? 6 : 1) void integrate_multi_inline(Mu
     const int wg_x = mp.z_fastest ? (int)blockIdx.z : (int)blockIdx.x, wg_y = (int)blockIdx.y;
     const int wg_z = mp.z_fastest ? (int)blockIdx.x : (int)blockIdx.z;
     if constexpr (SHORT) {
-        // Patch classification, once per workgroup: its voxels lie in one rectangle of the slice (256 x 4 voxels in
-        // the row mapping, 1024 consecutive voxels in the flat one).  The first wavefront stages the frame blocks in
-        // LDS (coalesced) and classifies one frame per lane; bit f of the two words then tells every wavefront of
-        // the workgroup what frame f does to all of its voxels.
+        // Patch classification in the prologue.  The first wavefront stages the frame blocks in LDS (coalesced); then
+        //   row / flat mapping: it classifies the workgroup's patch (256 x 4 voxels, or 1024 consecutive ones), one frame
+        //     per lane, and bit f of two words in LDS tells every wavefront what frame f does to all of its voxels;
+        //   BRICK: every wavefront classifies its own 64 x 4 brick, one frame per lane, and keeps the two words itself.
         __shared__ FramePose s_frames[kMaxFramesPerLaunch];
         __shared__ unsigned int s_bits[2];
+        __shared__ unsigned int s_claims[2];   // BRICK: (free, skipped) wavefront-frames of the workgroup, and
+        __shared__ unsigned int s_done;        //        how many of its wavefronts have added theirs
         static_assert(sizeof(FramePose) % 8 == 0, "staged as 8-byte words");
+        const IntegrateParams &p = mp.common;
+        const int lane = threadIdx.x;
         if (threadIdx.y == 0) {
-            const IntegrateParams &p = mp.common;
-            const int lane = threadIdx.x;
             constexpr int kWords = (int)(sizeof(FramePose) * kMaxFramesPerLaunch / 8);
             const unsigned long long __attribute__((address_space(4))) *src =
                 (const unsigned long long __attribute__((address_space(4))) *)frames;
             unsigned long long *dst = reinterpret_cast<unsigned long long *>(s_frames);
             for (int k = lane; k < kWords; k += 64) dst[k] = src[k];
-            int xa, xb, ya, yb;
-            if constexpr (FLAT) {
-                const int i0 = wg_x * 1024;
-                const int i1 = min(i0 + 1023, p.quads_per_slice * 4 - 1);
-                ya = i0 / p.dim_x;
-                yb = i1 / p.dim_x;
-                xa = ya == yb ? i0 - ya * p.dim_x : 0;
-                xb = ya == yb ? i1 - yb * p.dim_x : p.dim_x - 1;
-            } else {
-                xa = wg_x * 256;
-                xb = min(xa + 255, p.dim_x - 1);
-                ya = wg_y * 4;
-                yb = min(ya + 3, p.dim_y - 1);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            int cls = 0;
-            if (lane < mp.n_frames) cls = classify_patch(p, s_frames + lane, xa, xb, ya, yb, p.z_begin + wg_z);
-            const unsigned long long fb = __ballot(cls == 1), sb = __ballot(cls == 2);
-            if (lane == 0) {
-                s_bits[0] = (unsigned int)fb;
-                s_bits[1] = (unsigned int)sb;
-                if (p.claim_counter != nullptr && (fb | sb) != 0ull)
-                    atomicAdd(p.claim_counter, ((unsigned long long)__popcll(fb) << 32) | (unsigned long long)__popcll(sb));
+            if constexpr (BRICK) { if (lane == 0) { s_claims[0] = 0u; s_claims[1] = 0u; s_done = 0u; } }
+            if constexpr (!BRICK) {
+                int xa, xb, ya, yb;
+                if constexpr (FLAT) {
+                    const int i0 = wg_x * 1024;
+                    const int i1 = min(i0 + 1023, p.quads_per_slice * 4 - 1);
+                    ya = i0 / p.dim_x;
+                    yb = i1 / p.dim_x;
+                    xa = ya == yb ? i0 - ya * p.dim_x : 0;
+                    xb = ya == yb ? i1 - yb * p.dim_x : p.dim_x - 1;
+                } else {
+                    xa = wg_x * 256;
+                    xb = min(xa + 255, p.dim_x - 1);
+                    ya = wg_y * 4;
+                    yb = min(ya + 3, p.dim_y - 1);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                int cls = 0;
+                if (lane < mp.n_frames) cls = classify_patch(p, s_frames + lane, xa, xb, ya, yb, p.z_begin + wg_z);
+                const unsigned long long fb = __ballot(cls == 1), sb = __ballot(cls == 2);
+                if (lane == 0) {
+                    s_bits[0] = (unsigned int)fb;
+                    s_bits[1] = (unsigned int)sb;
+                    if (p.claim_counter != nullptr && (fb | sb) != 0ull)
+                        atomicAdd(p.claim_counter, ((unsigned long long)__popcll(fb) << 32) | (unsigned long long)__popcll(sb));
+                }
             }
         }
         __syncthreads();
-        free_frames = s_bits[0];
-        skip_frames = s_bits[1];
+        if constexpr (BRICK) {
+            const int xa = wg_x * 256 + (int)threadIdx.y * 64, ya = wg_y * 4;
+            int cls = 0;
+            if (xa < p.dim_x && lane < mp.n_frames)
+                cls = classify_patch(p, s_frames + lane, xa, min(xa + 63, p.dim_x - 1), ya, min(ya + 3, p.dim_y - 1), p.z_begin + wg_z);
+            const unsigned long long fb = __ballot(cls == 1), sb = __ballot(cls == 2);
+            free_frames = (unsigned int)fb;
+            skip_frames = (unsigned int)sb;
+            if (p.claim_counter != nullptr && lane == 0) {
+                // one global atomic per workgroup: the wavefronts add up in LDS, the last one to arrive passes the sum on
+                if (fb != 0ull) atomicAdd(&s_claims[0], (unsigned)__popcll(fb));
+                if (sb != 0ull) atomicAdd(&s_claims[1], (unsigned)__popcll(sb));
+                __threadfence_block();
+                if (atomicAdd(&s_done, 1u) == 3u) {
+                    __threadfence_block();
+                    const unsigned long long nf = s_claims[0], ns = s_claims[1];
+                    if ((nf | ns) != 0ull) atomicAdd(p.claim_counter, (nf << 32) | ns);
+                }
+            }
+        } else {
+            free_frames = s_bits[0];
+            skip_frames = s_bits[1];
+        }
         free_frames = __builtin_amdgcn_readfirstlane(free_frames);
         skip_frames = __builtin_amdgcn_readfirstlane(skip_frames);
     }
-    multi_body<R, NT, FLAT, LABELS, MASKS, SHORT>(mp.common, (const FramePose *)frames, mp.n_frames, wg_x, wg_y, wg_z,
-                                                  mp.labels, free_frames, skip_frames);
+    multi_body<R, NT, FLAT, LABELS, MASKS, SHORT, BRICK>(mp.common, (const FramePose *)frames, mp.n_frames, wg_x, wg_y, wg_z,
+                                                         mp.labels, free_frames, skip_frames);
 }
 
 // Experiment (variant 5): XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs, so

@@ -3,8 +3,8 @@ workgroups classify: depth discontinuities exactly on the 16-pixel tile borders 
 stop, patches whose projected box touches the image borders +- the pixel margin, cameras whose distance puts the
 patch corners at the cz_short threshold, non-finite and invalid pixels inside otherwise claimable tiles.
 
-Every case runs the fused sequence path with the classification forced on (variant 8), decided per launch
-(variant 0) and forbidden (variant 7), and must equal the oracle bit for bit; with it forced on, claims must
+Every case runs the fused sequence path with the classification forced on (variant 8: 64 x 4 bricks classified per
+wavefront; variant 11: 256 x 1 rows classified per workgroup), decided per launch (variant 0) and forbidden (variant 7), and must equal the oracle bit for bit; with it forced on, claims must
 actually be made (counters), so the test is about claims that are right, not claims that are absent."""
 import numpy as np
 import pytest
@@ -26,13 +26,13 @@ def run_case(cuda, oracle, dims, vs, origin, K, frames, expect_claims=True, trun
             oracle.integrate(cfg.cam_K, c2w, depth, dims, origin, vs, cfg.trunc_margin, ref_t, ref_w, threads=8)
     keep = [cuda.from_numpy(np.ascontiguousarray(d, np.float32)).cuda() for _, d in frames]
     poses = np.stack([p for p, _ in frames])
-    for variant in (8, 0, 7):
+    for variant in (8, 11, 0, 7):     # bricks per wavefront / rows per workgroup (both forced), per launch, never
         with capi.Volume(cfg) as vol:
             vol.set_kernel_variant(variant)
-            if variant == 8:
+            if variant in (8, 11):
                 vol.shortcut_stats(True)
             vol.integrate_frames_device([d.data_ptr() for d in keep], poses)
-            if variant == 8:
+            if variant in (8, 11):
                 per_voxel, free, skipped = vol.shortcut_stats(False)
                 assert per_voxel + free + skipped > 0
                 if expect_claims:
