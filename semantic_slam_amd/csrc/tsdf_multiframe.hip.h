@@ -465,19 +465,44 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
     };
 
     // not unrolled: one frame's temporaries at a time (unrolling interleaves frames: 100 VGPRs)
+    // SHORT: the loop visits only the frames that are not skipped (bit scan over the claim word: a wavefront most of
+    // whose frames see nothing does not pay a loop iteration of scalar bookkeeping for each of them)
+    unsigned int todo = n_frames >= 32 ? 0xffffffffu : ((1u << n_frames) - 1u);
+    if constexpr (SHORT) {
+        if (p.shortcut_stats != nullptr && (threadIdx.x & 63) == 0 && (skip_frames & todo) != 0u)
+            atomicAdd(p.shortcut_stats + 2, (unsigned)__popc(skip_frames & todo));
+        todo &= ~skip_frames;
+    }
 #pragma unroll 1
     for (int f = 0; f < n_frames; ++f) {
         if constexpr (SHORT) {
-            const bool skip = (skip_frames >> f) & 1u, all_free = (free_frames >> f) & 1u;
-            if (p.shortcut_stats != nullptr && (threadIdx.x & 63) == 0)
-                atomicAdd(p.shortcut_stats + (skip ? 2 : all_free ? 1 : 0), 1u);
-            if (skip) continue;
+            if (todo == 0u) break;
+            f = __ffs((int)todo) - 1;      // the next frame that does something; wave-uniform
+            todo &= todo - 1u;
+            const bool all_free = (free_frames >> f) & 1u;
             if (all_free) {
                 // every voxel of the wavefront: valid pixel, diff >= trunc (dist = 1), none in the band
                 if (__ballot(!(touched[0] && ones[0] && (fl[0] & 2u))) == 0ull) {   // steady state of free-space rows: only the weights move
+                    // ... and a run of such frames moves them by its length at once, when that is the same bits: every
+                    // weight an integer below 2^24 - 32, so that each of the run's "+ 1" is exact and so is their sum
+                    const unsigned int rest = ~(free_frames >> f);
+                    unsigned int run = rest != 0u ? (unsigned)(__ffs((int)rest) - 1) : 32u - (unsigned)f;   // >= 1
+                    run = min(run, (unsigned)(n_frames - f));
+                    const float4 w = w4[0];
+                    const bool whole = w.x == truncf(w.x) && w.y == truncf(w.y) && w.z == truncf(w.z) && w.w == truncf(w.w) &&
+                                       fmaxf(fmaxf(w.x, w.y), fmaxf(w.z, w.w)) < 16777184.0f;
+                    if (run > 1u && __ballot(!whole) == 0ull) {
+                        const float k = (float)run;
+                        w4[0].x += k; w4[0].y += k; w4[0].z += k; w4[0].w += k;
+                        todo &= ~((run >= 32u ? 0xffffffffu : ((1u << run) - 1u)) << f);
+                        if (p.shortcut_stats != nullptr && (threadIdx.x & 63) == 0) atomicAdd(p.shortcut_stats + 1, run);
+                        continue;
+                    }
+                    if (p.shortcut_stats != nullptr && (threadIdx.x & 63) == 0) atomicAdd(p.shortcut_stats + 1, 1u);
                     w4[0].x += 1.0f; w4[0].y += 1.0f; w4[0].z += 1.0f; w4[0].w += 1.0f;
                     continue;
                 }
+                if (p.shortcut_stats != nullptr && (threadIdx.x & 63) == 0) atomicAdd(p.shortcut_stats + 1, 1u);
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     rowany[r] = true;
@@ -489,6 +514,9 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
                 apply_frame();
                 continue;
             }
+        }
+        if constexpr (SHORT) {
+            if (p.shortcut_stats != nullptr && (threadIdx.x & 63) == 0) atomicAdd(p.shortcut_stats, 1u);
         }
         any = false;
         band = false;
