@@ -158,3 +158,41 @@ def test_classification_is_dropped_when_it_claims_nothing_and_probed_again(cuda,
         assert frac > 0.9 and idle == 0
         t, w = vol.download()
     assert np.array_equal(w, ref_w) and np.array_equal(t.view(np.uint32), ref_t.view(np.uint32))
+
+
+@pytest.mark.parametrize("variant", [8, 11])
+def test_runs_of_free_space_frames_with_awkward_weights(cuda, oracle, variant):
+    """A run of claimed free-space frames moves the weights by its length at once -- only when that is the same bits
+    as that many "+ 1": weights that are not integers (an upload), weights at and around 2^24 (where w + 1 == w) and
+    ordinary counts, all with TSDF = 1 so that the free-space path is taken; the run is interrupted by a frame that
+    sees nothing and one with a surface inside the volume.  Bit-exact against the oracle, classification forced on."""
+    dims, vs = (256, 16, 12), 0.002
+    origin = synth.surf_volume(256, vs, 0.7)
+    cfg = capi.make_config(dims, vs, origin)
+    far = origin[2] + dims[2] * vs
+    n = dims[0] * dims[1] * dims[2]
+    rng = np.random.default_rng(4)
+    w0 = rng.choice(np.array([0.0, 3.0, 0.5, 2.75, 16777215.0, 16777216.0, 16777184.0, 16777183.0, 16777150.0, 8388607.5,
+                              3.9999998, 1e7], np.float32), n).astype(np.float32)
+    w0[: 256 * 16] = 5.0                      # one slice of plain counts (the aggregated path must fire somewhere)
+    t0 = np.ones(n, np.float32)
+    free = np.full((480, 640), far + 0.5, np.float32)
+    none = np.full((480, 640), origin[2] - 0.2, np.float32)
+    band = np.full((480, 640), far - 0.01, np.float32)
+    depths = [free] * 9 + [none] + [free] * 7 + [band] + [free] * 16 + [free] * 5      # 39 frames: two passes
+    pose = synth.identity_pose()
+    ref_t, ref_w = t0.copy(), w0.copy()
+    for d in depths:
+        oracle.integrate(cfg.cam_K, pose, d, dims, origin, vs, cfg.trunc_margin, ref_t, ref_w)
+    keep = {id(d): cuda.from_numpy(d).cuda() for d in (free, none, band)}
+    with capi.Volume(cfg) as vol:
+        vol.set_kernel_variant(variant)
+        vol.upload(t0, w0)
+        vol.shortcut_stats(True)
+        vol.integrate_frames_device([keep[id(d)].data_ptr() for d in depths], np.stack([pose] * len(depths)))
+        per_voxel, fr, sk = vol.shortcut_stats(False)
+        t, w = vol.download()
+    assert fr > 0 and sk > 0
+    assert np.array_equal(w, ref_w), f"{np.count_nonzero(w != ref_w)} weights differ, e.g. {w[w != ref_w][:4]} vs {ref_w[w != ref_w][:4]}"
+    assert np.array_equal(t.view(np.uint32), ref_t.view(np.uint32))
+    assert ref_w[0] == 5.0 + 38.0 or ref_w[0] == 5.0 + 37.0     # counts moved by the frames that saw the voxel
