@@ -171,6 +171,20 @@ tsdfk::IntegrateParams make_params(const tsdf_volume *v, const float *depth_dev,
     p.quads_per_row = c.dim_x / 4;
     p.quads_per_slice = (int)((int64_t)c.dim_x * c.dim_y / 4);
     p.chunks_per_slice = v->chunks_per_slice;
+    // brick view (tsdf_multiframe.hip.h, BRICK): the widest brick row of at most 16 quads that divides a row, as many
+    // rows as fit 64 lanes; none when a row only divides into pieces narrower than 8 quads (poorly coalesced)
+    p.brick_q = 0; p.brick_r = 0; p.bricks_per_group = 0; p.brick_groups = 0;
+    if (c.dim_x % 4 == 0) {
+        for (int q = 16; q >= 8; --q) {
+            if (p.quads_per_row % q == 0) {
+                p.brick_q = q;
+                p.brick_r = 64 / q;
+                p.bricks_per_group = p.quads_per_row / q;
+                p.brick_groups = (c.dim_y + p.brick_r - 1) / p.brick_r;
+                break;
+            }
+        }
+    }
     // The shared-reciprocal projection (tsdf_kernels.hip.h, fast_div2) is exact when no operand
     // needs div_scale's pre-scaling: bound every camera-frame coordinate of the slab by
     // sum_j |R_ij| * max|d_j| and keep it, and the intrinsics, far from the exponent limits.
@@ -589,10 +603,21 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
                 for (int f = 0; f < n; ++f) mi.frames[f].tiles = v->d_tiles + (size_t)f * per_frame;
                 for (int f = n; f < tsdfk::kMaxFramesPerLaunch; ++f) mi.frames[f] = mi.frames[0];
             }
-            if (v->flat && any_mask && classify)
+            // classified launches use the brick view wherever a row divides into bricks (variant 11: round 1's shapes --
+            // rows / 1024 consecutive voxels, classified per workgroup -- for A/B and tests)
+            const bool bricks = classify && v->variant != 11 && mi.common.brick_q > 0;
+            dim3 grid_bricks(1, 1, 1);
+            if (bricks) {
+                const unsigned wgs = (unsigned)(((int64_t)mi.common.brick_groups * mi.common.bricks_per_group + 3) / 4);
+                if (wgs > 65535u) mi.z_fastest = 0;   // the slow grid dimensions hold 65535 at most
+                grid_bricks = mi.z_fastest ? dim3((unsigned)nz, 1, wgs) : dim3(wgs, 1, (unsigned)nz);
+            }
+            if (bricks && any_mask)
+                hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, false, true, true, true>), grid_bricks, block, 0, v->stream, mi);
+            else if (bricks)
+                hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, false, false, true, true>), grid_bricks, block, 0, v->stream, mi);
+            else if (v->flat && any_mask && classify)
                 hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, true, false, true, true>), grid_flat, block, 0, v->stream, mi);
-            else if (!v->flat && any_mask && classify && v->variant != 11)
-                hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, false, true, true, true>), grid_rows, block, 0, v->stream, mi);
             else if (!v->flat && any_mask && classify)
                 hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, false, true, true>), grid_rows, block, 0, v->stream, mi);
             else if (v->flat && any_mask)
@@ -603,16 +628,14 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
                 hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, true, false, false>), grid_flat, block, 0, v->stream, mi);
             else if (any_mask)
                 hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, false, true>), grid_rows, block, 0, v->stream, mi);
-            else if (classify && v->variant != 11)   // bricks: 64 x 4 voxels per wavefront, classified per wavefront
-                hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, false, false, true, true>), grid_rows, block, 0, v->stream, mi);
-            else if (classify)                       // variant 11: rows, classified per workgroup (round 1's shape; A/B)
+            else if (classify)
                 hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, false, false, true>), grid_rows, block, 0, v->stream, mi);
             else
                 hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, false, false>), grid_rows, block, 0, v->stream, mi);
             if (count_claims) {
-                const dim3 &g = v->flat ? grid_flat : grid_rows;
+                const dim3 &g = bricks ? grid_bricks : v->flat ? grid_flat : grid_rows;
                 // claims are counted per workgroup-frame, with bricks per wavefront-frame (four per workgroup)
-                v->claims_total = (double)g.x * g.y * g.z * n * ((!v->flat && v->variant != 11) ? 4.0 : 1.0);
+                v->claims_total = (double)g.x * g.y * g.z * n * (bricks ? 4.0 : 1.0);
                 HIP_TRY(hipMemcpyAsync(v->h_claims, v->d_claims, sizeof(unsigned long long), hipMemcpyDeviceToHost, v->stream));
                 HIP_TRY(hipEventRecord(v->claims_done, v->stream));
                 v->claims_pending = true;

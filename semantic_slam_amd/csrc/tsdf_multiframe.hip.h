@@ -310,14 +310,16 @@ struct MultiParamsInline {
 // no mask bytes, defaults or null tests (2 of 44 VALU instructions per voxel-frame).
 // SHORT: the frames of the launch that come with depth tile tables are classified per wavefront in the prologue, one
 // lane per frame (classify_patch): all voxels updated with dist = 1, or none updated, without projecting any of them.
-// BRICK (row mapping only): the workgroup's 256 x 4 voxels are dealt to its wavefronts as four 64(x) x 4(y) bricks instead
-// of four 256 x 1 rows -- lane l of wavefront w owns the quad (w * 16 + (l & 15)) of row (l >> 4).  A wave-instruction
-// then touches four 256-byte row pieces instead of one 1-KiB piece (the fused launches are bound by instruction issue,
-// not by HBM), and the wavefront's voxels project onto a compact pixel box, so a depth tile table can decide far more
-// wavefront-frames without projecting a voxel: on S-surf an ideal classifier claims 38 % of the 256 x 1 rows but 77 % of
-// the 64 x 4 bricks (a row crosses both image borders and every silhouette on its way).  The free-space summary keeps its
-// layout (one word per 256-voxel row segment, now shared by the four wavefronts of a workgroup): a set bit was true for
-// the whole segment at launch start, each wavefront only changes its own voxels, and clearing is idempotent.
+// BRICK: a wavefront owns a compact brick of the slice -- brick_q quads of brick_r consecutive rows (IntegrateParams:
+// 64 x 4 voxels for 512-voxel rows, 40 x 6 for the reference's 200-voxel rows) -- instead of 256 consecutive voxels; b0 =
+// workgroup index within the slice, four consecutive bricks per workgroup, lane l owns quad (l % brick_q) of the brick's
+// row (l / brick_q).  A wave-instruction then touches brick_r row pieces of 16 * brick_q bytes instead of one 1-KiB piece
+// (the fused launches are bound by instruction issue, not by HBM), and the wavefront's voxels project onto a compact
+// pixel box, so a depth tile table can decide far more wavefront-frames without projecting a voxel: on S-surf an ideal
+// classifier claims 38 % of 256 x 1 rows but 77 % of 64 x 4 bricks (a row crosses both image borders and every
+// silhouette on its way).  The free-space summary keeps its layout (one word per 256-voxel chunk or row segment, now
+// shared by several wavefronts): a set bit was true for the whole chunk at launch start, each lane only changes its own
+// voxels -- `ones` is per lane here: "the chunk's bit was set and MY quad is still all ones" -- and clearing is idempotent.
 template <int R, bool NT, bool FLAT, bool LABELS = false, bool MASKS = true, bool SHORT = false, bool BRICK = false>
 __device__ __forceinline__ void multi_body(const IntegrateParams &p, const FramePose *__restrict__ frames,
                                            const int n_frames, const int b0, const int b1, const int lz,
@@ -327,15 +329,23 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
     static_assert(!SHORT || R == 1, "patch classification is written for one row per lane");
     static_assert(!LABELS || R == 1, "label fusion rides on the one-row kernel");
     static_assert(!FLAT || R == 1, "the flat mapping handles one quad per lane");
-    static_assert(!BRICK || (R == 1 && !FLAT), "bricks re-deal the row mapping's workgroup");
+    static_assert(!BRICK || (R == 1 && !FLAT), "bricks are their own mapping");
     int xg, gy0;
     size_t row0, flag0;
+    // the summary word of the lane's quad: row segment (dim_x % 256 == 0) or 256-voxel chunk of the slice's linear view
+    auto brick_flag_index = [&](const int gy, const int quad) -> size_t {
+        if (p.nseg > 0) return ((size_t)lz * p.dim_y + gy) * (size_t)p.nseg + (size_t)(quad >> 6);
+        return (size_t)lz * p.chunks_per_slice + (size_t)((gy * p.quads_per_row + quad) >> 6);
+    };
     if constexpr (BRICK) {
-        xg = b0 * 64 + (int)threadIdx.y * 16 + ((int)threadIdx.x & 15);
-        gy0 = b1 * 4 + ((int)threadIdx.x >> 4);
-        if (xg >= p.xgroups || gy0 >= p.dim_y) return;
+        const int brick = b0 * 4 + (int)threadIdx.y;
+        const int g = brick / p.bricks_per_group, i = brick - g * p.bricks_per_group;
+        const int rr = (int)threadIdx.x / p.brick_q, qq = (int)threadIdx.x - rr * p.brick_q;
+        xg = i * p.brick_q + qq;
+        gy0 = g * p.brick_r + rr;
+        if (g >= p.brick_groups || rr >= p.brick_r || gy0 >= p.dim_y) return;
         row0 = ((size_t)lz * p.dim_y + gy0) * (size_t)p.dim_x + (size_t)xg * 4;
-        flag0 = ((size_t)lz * p.dim_y + gy0) * (size_t)p.nseg + b0;
+        flag0 = brick_flag_index(gy0, xg);
     } else if constexpr (FLAT) {
         const int chunk = b0 * 4 + threadIdx.y;
         const int q = chunk * 64 + threadIdx.x;
@@ -355,7 +365,7 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
 
     // ---- voxel state held in registers across the frames ----------------------------------------
     uint32_t fl[R];
-    bool ones[R];            // every TSDF value of the lane's row segment is (still) exactly 1 (wave-uniform unless BRICK)
+    bool ones[R];            // every TSDF value of the row segment is (still) exactly 1 (wave-uniform); BRICK: see above
     float4 t4[R], w4[R];
     bool touched[R], tchanged[R];
 #pragma unroll
@@ -458,7 +468,7 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
             tchanged[r] |= changed;
             {   // a value != 1 appeared in the row segment: for every lane of the wavefront that shares the row
                 const unsigned long long nb = __ballot(notone);
-                if constexpr (BRICK) { if ((nb >> (((unsigned)threadIdx.x >> 4) * 16u)) & 0xffffull) ones[r] = false; }
+                if constexpr (BRICK) { if (notone) ones[r] = false; }   // per lane: it is this lane that clears the word
                 else { if (nb != 0ull) ones[r] = false; }
             }
         }
@@ -690,9 +700,8 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
             vol_store<NT>(p.weight + row0 + (size_t)r * p.dim_x, w4[r]);
         }
         if ((fl[r] & 1u) && !ones[r]) {
-            if constexpr (BRICK) {   // the word's index again from the lane's row (not kept live across the frame loop)
-                const int gy = b1 * 4 + ((int)threadIdx.x >> 4);
-                p.flags[((size_t)lz * p.dim_y + gy) * (size_t)p.nseg + b0] = fl[r] & 2u;
+            if constexpr (BRICK) {
+                p.flags[brick_flag_index(gy0, xg)] = fl[r] & 2u;
             } else {
                 p.flags[flag0 + (size_t)r * p.nseg] = fl[r] & 2u;
             }
@@ -725,7 +734,7 @@ __global__ __launch_bounds__(256, R == 2 ? 6 : (BRICK ? TSDF_BRICK_WAVES : 1)) v
         // Patch classification in the prologue.  The first wavefront stages the frame blocks in LDS (coalesced); then
         //   row / flat mapping: it classifies the workgroup's patch (256 x 4 voxels, or 1024 consecutive ones), one frame
         //     per lane, and bit f of two words in LDS tells every wavefront what frame f does to all of its voxels;
-        //   BRICK: every wavefront classifies its own 64 x 4 brick, one frame per lane, and keeps the two words itself.
+        //   BRICK: every wavefront classifies its own brick, one frame per lane, and keeps the two words itself.
         __shared__ FramePose s_frames[kMaxFramesPerLaunch];
         __shared__ unsigned int s_bits[2];
         __shared__ unsigned int s_claims[2];   // BRICK: (free, skipped) wavefront-frames of the workgroup, and
@@ -770,10 +779,13 @@ __global__ __launch_bounds__(256, R == 2 ? 6 : (BRICK ? TSDF_BRICK_WAVES : 1)) v
         }
         __syncthreads();
         if constexpr (BRICK) {
-            const int xa = wg_x * 256 + (int)threadIdx.y * 64, ya = wg_y * 4;
+            const int brick = wg_x * 4 + (int)threadIdx.y;
+            const int g = brick / p.bricks_per_group, i = brick - g * p.bricks_per_group;
+            const int xa = i * p.brick_q * 4, ya = g * p.brick_r;
             int cls = 0;
-            if (xa < p.dim_x && lane < mp.n_frames)
-                cls = classify_patch(p, s_frames + lane, xa, min(xa + 63, p.dim_x - 1), ya, min(ya + 3, p.dim_y - 1), p.z_begin + wg_z);
+            if (g < p.brick_groups && lane < mp.n_frames)
+                cls = classify_patch(p, s_frames + lane, xa, xa + p.brick_q * 4 - 1, ya, min(ya + p.brick_r - 1, p.dim_y - 1),
+                                     p.z_begin + wg_z);
             const unsigned long long fb = __ballot(cls == 1), sb = __ballot(cls == 2);
             free_frames = (unsigned int)fb;
             skip_frames = (unsigned int)sb;
