@@ -136,6 +136,8 @@ struct tsdf_batch {
     float2 *d_tiles;
     size_t tiles_per_object;
     uint8_t *d_wg_class;
+    uint8_t *d_brick_class;      // class per wavefront brick of the launch (classify_bricks_batched), on first use
+    size_t brick_class_bytes;
 };
 
 namespace {
@@ -270,8 +272,9 @@ bool tiles_fit(const tsdfk::IntegrateParams &p) { return (int64_t)p.tiles_w * p.
 
 // One-frame masked launches are classified per workgroup when the launch is large enough to repay the three small
 // dependent dispatches ahead of it (tile summary, sparse table, class table: ~25 us on the stream).  Measured
-// (tools/batch_time.py, instance masks over 12 % of the image): 16 x 200^3 batched 0.274 -> 0.204 ms per frame, one
-// 400^3 volume 0.095 -> 0.075; but 4 x 200^3 batched 0.083 -> 0.094 and one 200^3 volume 0.016 -> 0.026.
+// (tools/batch_time.py, instance masks over 12 % of the image): 16 x 200^3 batched 0.275 -> 0.157 ms per frame (wavefront
+// bricks; 0.201 with 1024-voxel workgroup patches), one 400^3 volume 0.095 -> 0.075; but 4 x 200^3 batched 0.083 -> 0.079
+// at best and one 200^3 volume 0.016 -> 0.026.
 // Variant 8 classifies regardless (tests), 7 never.
 constexpr int64_t kClassifyMinVoxels = 48000000;
 bool classify_one_frame(const tsdf_volume *v, int64_t launch_voxels)
@@ -1584,6 +1587,7 @@ int tsdf_batch_destroy(tsdf_batch *b)
     if (b->d_slice_map) (void)hipFree(b->d_slice_map);
     if (b->d_tiles) (void)hipFree(b->d_tiles);
     if (b->d_wg_class) (void)hipFree(b->d_wg_class);
+    if (b->d_brick_class) (void)hipFree(b->d_brick_class);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
     return TSDF_OK;
@@ -1604,7 +1608,7 @@ int tsdf_batch_create(const tsdf_config *cfgs, int32_t n, tsdf_batch **out)
     if (!b) return fail(TSDF_ERR_INVALID, "tsdf_batch_create: out of host memory");
     b->device = cfgs[0].device;
     b->stream = nullptr; b->d_slice_map = nullptr; b->slot_next = 0;
-    b->d_tiles = nullptr; b->tiles_per_object = 0; b->d_wg_class = nullptr;
+    b->d_tiles = nullptr; b->tiles_per_object = 0; b->d_wg_class = nullptr; b->d_brick_class = nullptr; b->brick_class_bytes = 0;
     b->total_slices = b->max_blocks = 0;
     for (int i = 0; i < kStageSlots; ++i) {
         b->h_params[i] = nullptr; b->d_params[i] = nullptr; b->h_poses[i] = nullptr; b->d_poses[i] = nullptr;
@@ -1689,7 +1693,10 @@ int tsdf_batch_integrate_device(tsdf_batch *b, const float *depth_dev, const uin
     for (int i = 1; i < n; ++i) same_range = same_range && b->vols[i]->cfg.max_depth == b->vols[0]->cfg.max_depth;
     int64_t launch_voxels = 0;
     for (tsdf_volume *v : b->vols) launch_voxels += v->n_vox;
-    const bool classify = any_mask && same_range && classify_one_frame(b->vols[0], launch_voxels) && tiles_fit(b->h_params[s][0]);
+    // ... and not for many small volumes: one tile table per object has to be built per frame (64 x 100^3: 0.231 -> 0.262 ms)
+    const bool big_enough = b->vols[0]->variant == 8 || launch_voxels >= (int64_t)n * 2000000;
+    const bool classify = any_mask && same_range && big_enough && classify_one_frame(b->vols[0], launch_voxels) &&
+                          tiles_fit(b->h_params[s][0]);
     if (classify) {
         const size_t per = tile_table_elems_host(b->h_params[s][0].tiles_w, b->h_params[s][0].tiles_h);
         if (!b->d_tiles) {
@@ -1705,7 +1712,28 @@ int tsdf_batch_integrate_device(tsdf_batch *b, const float *depth_dev, const uin
     HIP_TRY(hipMemcpyAsync(b->d_params[s], b->h_params[s], n * sizeof(tsdfk::IntegrateParams), hipMemcpyHostToDevice, b->stream));
     HIP_TRY(hipMemcpyAsync(b->d_poses[s], b->h_poses[s], n * sizeof(tsdfk::FramePose), hipMemcpyHostToDevice, b->stream));
     dim3 block(64, 4, 1), grid(b->max_blocks, 1, b->total_slices);
-    if (classify) {
+    // bricks when every object's rows divide into them (first volume on variant 11: workgroup patches, round-2a shape)
+    int brick_blocks = 0;
+    bool bricks = classify && b->vols[0]->variant != 11;
+    for (int i = 0; i < n && bricks; ++i) {
+        const tsdfk::IntegrateParams &q = b->h_params[s][i];
+        bricks = q.brick_q > 0;
+        brick_blocks = std::max(brick_blocks, (q.brick_groups * q.bricks_per_group + 3) / 4);
+    }
+    if (bricks) {
+        const size_t n_bricks = (size_t)brick_blocks * b->total_slices * 4;
+        if (b->brick_class_bytes < n_bricks) {
+            if (b->d_brick_class) HIP_TRY(hipFree(b->d_brick_class));
+            b->d_brick_class = nullptr;
+            b->brick_class_bytes = 0;
+            HIP_TRY(hipMalloc((void **)&b->d_brick_class, n_bricks));
+            b->brick_class_bytes = n_bricks;
+        }
+        hipLaunchKernelGGL(tsdfk::classify_bricks_batched, dim3((unsigned)((n_bricks + 255) / 256)), dim3(256), 0, b->stream,
+                           b->d_params[s], b->d_poses[s], b->d_slice_map, b->d_brick_class, brick_blocks, b->total_slices);
+        hipLaunchKernelGGL((tsdfk::integrate_multi_batched_bricks<true>), dim3(brick_blocks, 1, b->total_slices), block, 0, b->stream,
+                           b->d_params[s], b->d_poses[s], b->d_slice_map, b->d_brick_class);
+    } else if (classify) {
         const size_t n_wg = (size_t)b->max_blocks * b->total_slices;
         hipLaunchKernelGGL(tsdfk::classify_workgroups_batched, dim3((unsigned)((n_wg + 255) / 256)), dim3(256), 0, b->stream,
                            b->d_params[s], b->d_poses[s], b->d_slice_map, b->d_wg_class, b->max_blocks, b->total_slices);

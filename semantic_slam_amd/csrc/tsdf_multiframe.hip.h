@@ -271,6 +271,28 @@ __global__ __launch_bounds__(256) void classify_workgroups_batched(const Integra
     cls[id] = (uint8_t)classify_wg_patch(p, poses + m.x, bx, 0, m.y, 0);
 }
 
+// The batched form with bricks: one thread per wavefront brick of the launch; index = (slice of the launch *
+// max_blocks + workgroup) * 4 + wavefront.  Each object brings its own brick view (IntegrateParams::brick_*).
+__global__ __launch_bounds__(256) void classify_bricks_batched(const IntegrateParams *__restrict__ params,
+                                                               const FramePose *__restrict__ poses,
+                                                               const int2 *__restrict__ slice_map, uint8_t *cls,
+                                                               int max_blocks, int total_slices)
+{
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= max_blocks * total_slices * 4) return;
+    const int wave = id & 3, wg = (id >> 2) % max_blocks, z = (id >> 2) / max_blocks;
+    const int2 m = slice_map[z];
+    const IntegrateParams p = params[m.x];
+    const int brick = wg * 4 + wave;
+    const int g = brick / p.bricks_per_group, i = brick - g * p.bricks_per_group;
+    int c = 2;                                   // a brick past the end of this object's slice: nothing there
+    if (g < p.brick_groups) {
+        const int xa = i * p.brick_q * 4, ya = g * p.brick_r;
+        c = classify_patch(p, poses + m.x, xa, xa + p.brick_q * 4 - 1, ya, min(ya + p.brick_r - 1, p.dim_y - 1), p.z_begin + m.y);
+    }
+    cls[id] = (uint8_t)c;
+}
+
 // Slab arrays of the per-voxel label state (tsdf_labels.hip.h), for the LABELS kernels.
 struct LabelState {
     uint16_t *label;
@@ -867,6 +889,21 @@ __global__ __launch_bounds__(256) void integrate_multi_batched(const IntegratePa
         multi_body<1, NT, true, false, true, true>(p, poses + m.x, 1, blockIdx.x, 0, m.y, LabelState(), c == 1u ? 1u : 0u, 0u);
     else
         multi_body<1, NT, true>(p, poses + m.x, 1, blockIdx.x, 0, m.y);
+}
+
+// The batched launch over bricks with a class per wavefront (classify_bricks_batched): per-object volumes are fed
+// depth x their instance mask, so most bricks of most objects see nothing -- by rows, slices AND columns.
+template <bool NT>
+__global__ __launch_bounds__(256, 8) void integrate_multi_batched_bricks(const IntegrateParams *__restrict__ params,
+                                                                        const FramePose *__restrict__ poses,
+                                                                        const int2 *__restrict__ slice_map,
+                                                                        const uint8_t *__restrict__ wg_class)
+{
+    const unsigned c = wg_class[(blockIdx.x + gridDim.x * blockIdx.z) * 4u + threadIdx.y];   // wave-uniform
+    if (c == 2u) return;
+    const int2 m = slice_map[blockIdx.z];
+    const IntegrateParams p = params[m.x];
+    multi_body<1, NT, false, false, true, true, true>(p, poses + m.x, 1, blockIdx.x, 0, m.y, LabelState(), c == 1u ? 1u : 0u, 0u);
 }
 
 }  // namespace tsdfk

@@ -1,7 +1,8 @@
 """Development probe: n object volumes of the reference's default size (200^3 @ 4 mm), one frame per call -- the
 reference's real call shape (one TSDF per object instance fed depth x its instance mask, ref: src/Engine.cpp:172-233,
 src/Object.cpp:67) -- as one batched launch and as n per-volume launches, each with and without the per-workgroup
-classification of masked frames (kernel variant 0: the library's size policy; 8: always; 7: never).
+classification of masked frames (kernel variant 0: the library's size policy; 8: always; 11: by policy with round 2a's
+1024-voxel workgroup patches instead of wavefront bricks; 7: never).
 
     python tools/batch_time.py [--n 16] [--edge 200] [--masks instance|full|none]
 """
@@ -49,8 +50,8 @@ frames = args.frames
 cover = float(np.mean([m.mean() / 255.0 for m in masks]))
 vox = n * E ** 3
 print(f"{n} volumes of {E}^3, masks: {args.masks} (mean coverage {cover:.2f} of the image)")
-NAMES = {0: "by policy", 8: "forced on", 7: "off      "}
-for cls in (0, 8, 7):
+NAMES = {0: "by policy (bricks)        ", 8: "forced on (bricks)        ", 11: "by policy (1024-voxel patches)", 7: "off                       "}
+for cls in (0, 8, 11, 7):
     with capi.Batch(cfgs) as batch:
         batch.volumes[0].set_kernel_variant(cls)
         for k in range(10):
