@@ -335,6 +335,35 @@ int classify_single(tsdf_volume *v, tsdfk::IntegrateParams &p, int nbx, int nby,
     return TSDF_OK;
 }
 
+// The same with wavefront bricks (rows that divide into them): class per brick, then the brick kernel.  Queues the launch.
+int launch_masked_bricks(tsdf_volume *v, tsdfk::IntegrateParams &p)
+{
+    const int blocks = (p.brick_groups * p.bricks_per_group + 3) / 4, nz = p.nz;
+    const size_t per = tile_table_elems_host(p.tiles_w, p.tiles_h);
+    if (!v->d_tiles) HIP_TRY(hipMalloc((void **)&v->d_tiles, tsdfk::kMaxFramesPerLaunch * per * sizeof(float2)));
+    const size_t n_bricks = (size_t)blocks * nz * 4;
+    if (v->wg_class_bytes < n_bricks) {
+        if (v->d_wg_class) HIP_TRY(hipFree(v->d_wg_class));
+        v->d_wg_class = nullptr;
+        v->wg_class_bytes = 0;
+        HIP_TRY(hipMalloc((void **)&v->d_wg_class, n_bricks));
+        v->wg_class_bytes = n_bricks;
+    }
+    const float *d = p.depth;
+    const uint8_t *m = p.mask;
+    int rc = build_tile_tables(v->stream, v->cfg, p, &d, &m, 1, v->d_tiles);
+    if (rc) return rc;
+    tsdfk::FramePose pose;
+    pose_from_params(pose, p);
+    pose.tiles = v->d_tiles;
+    hipLaunchKernelGGL(tsdfk::classify_bricks, dim3((unsigned)((n_bricks + 255) / 256)), dim3(256), 0, v->stream, p, pose,
+                       v->d_wg_class, blocks, nz);
+    p.wg_class = v->d_wg_class;
+    hipLaunchKernelGGL((tsdfk::integrate_single_bricks<true>), dim3(blocks, 1, nz), dim3(64, 4, 1), 0, v->stream, p, pose);
+    HIP_TRY(hipGetLastError());
+    return TSDF_OK;
+}
+
 // Kernel variants (tsdf_set_kernel_variant):
 //   0        default: integrate_tile<2, elide, nt, summary, fast> when dim_x % 4 == 0, else the scalar
 //            kernel; frame sequences (tsdf_integrate_frames_device, ..._sequence_timed) go through
@@ -435,7 +464,10 @@ int launch_integrate(tsdf_volume *v, const float *depth_dev, const uint8_t *mask
         // masked fusion uses the default configuration; per-object volumes see their instance only, so the workgroups
         // the tile table of depth x mask proves untouched are told to leave (variant 7: never)
         const dim3 grid((p.xgroups + 63) / 64, (p.dim_y + 7) / 8, p.nz);
-        if (classify_one_frame(v, v->n_vox) && tiles_fit(p)) {
+        if (classify_one_frame(v, v->n_vox) && tiles_fit(p) && p.brick_q > 0 && v->variant != 11) {
+            int rc = launch_masked_bricks(v, p);    // per wavefront brick: skipped by rows, slices and columns
+            if (rc) return rc;
+        } else if (classify_one_frame(v, v->n_vox) && tiles_fit(p)) {
             int rc = classify_single(v, p, (int)grid.x, (int)grid.y, (int)grid.z, 8);
             if (rc) return rc;
             hipLaunchKernelGGL((tsdfk::integrate_tile<2, true, true, true, true, false, true, false, true>), grid, dim3(64, 4, 1), 0,
@@ -512,7 +544,11 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
         std::memcpy(v->last_cam2base, c2b, sizeof v->last_cam2base);
         v->flags_known_zero = false;
         dim3 block(64, 4, 1);
-        if (v->flat && pose.mask != nullptr && classify_one_frame(v, v->n_vox) && tiles_fit(common)) {
+        if (v->flat && pose.mask != nullptr && classify_one_frame(v, v->n_vox) && tiles_fit(common) && common.brick_q > 0 &&
+            v->variant != 11) {
+            tsdfk::IntegrateParams cp = make_params(v, depth_dev[0], pose.mask, c2b, 4);
+            return launch_masked_bricks(v, cp);
+        } else if (v->flat && pose.mask != nullptr && classify_one_frame(v, v->n_vox) && tiles_fit(common)) {
             // one masked frame into a flat-mapped volume (the reference's 200^3 object grids): classified per workgroup
             dim3 grid((v->chunks_per_slice + 3) / 4, 1, nz);
             tsdfk::IntegrateParams cp = make_params(v, depth_dev[0], pose.mask, c2b, 4);

@@ -271,6 +271,23 @@ __global__ __launch_bounds__(256) void classify_workgroups_batched(const Integra
     cls[id] = (uint8_t)classify_wg_patch(p, poses + m.x, bx, 0, m.y, 0);
 }
 
+// One masked frame into one volume, with bricks: the class of every wavefront brick, one thread per brick; index =
+// (slice * blocks + workgroup) * 4 + wavefront, blocks = workgroups per slice.
+__global__ __launch_bounds__(256) void classify_bricks(IntegrateParams p, FramePose pose, uint8_t *cls, int blocks, int nz)
+{
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= blocks * nz * 4) return;
+    const int wave = id & 3, wg = (id >> 2) % blocks, lz = (id >> 2) / blocks;
+    const int brick = wg * 4 + wave;
+    const int g = brick / p.bricks_per_group, i = brick - g * p.bricks_per_group;
+    int c = 2;
+    if (g < p.brick_groups) {
+        const int xa = i * p.brick_q * 4, ya = g * p.brick_r;
+        c = classify_patch(p, &pose, xa, xa + p.brick_q * 4 - 1, ya, min(ya + p.brick_r - 1, p.dim_y - 1), p.z_begin + lz);
+    }
+    cls[id] = (uint8_t)c;
+}
+
 // The batched form with bricks: one thread per wavefront brick of the launch; index = (slice of the launch *
 // max_blocks + workgroup) * 4 + wavefront.  Each object brings its own brick view (IntegrateParams::brick_*).
 __global__ __launch_bounds__(256) void classify_bricks_batched(const IntegrateParams *__restrict__ params,
@@ -889,6 +906,15 @@ __global__ __launch_bounds__(256) void integrate_multi_batched(const IntegratePa
         multi_body<1, NT, true, false, true, true>(p, poses + m.x, 1, blockIdx.x, 0, m.y, LabelState(), c == 1u ? 1u : 0u, 0u);
     else
         multi_body<1, NT, true>(p, poses + m.x, 1, blockIdx.x, 0, m.y);
+}
+
+// One masked frame into one volume over bricks with a class per wavefront (classify_bricks).
+template <bool NT>
+__global__ __launch_bounds__(256, 8) void integrate_single_bricks(IntegrateParams p, FramePose pose)
+{
+    const unsigned c = p.wg_class[(blockIdx.x + gridDim.x * blockIdx.z) * 4u + threadIdx.y];   // wave-uniform
+    if (c == 2u) return;
+    multi_body<1, NT, false, false, true, true, true>(p, &pose, 1, blockIdx.x, 0, blockIdx.z, LabelState(), c == 1u ? 1u : 0u, 0u);
 }
 
 // The batched launch over bricks with a class per wavefront (classify_bricks_batched): per-object volumes are fed
