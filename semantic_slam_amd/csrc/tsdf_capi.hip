@@ -581,15 +581,7 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
         // more than the L2s hold) they gather from.  Measured at 512^3 S-surf with a depth frame per pose: 0.1325 ->
         // 0.1148 ms per frame; 1024^3 on the fr3 trajectory 0.529 -> 0.376; no change with one resident frame.
         mi.z_fastest = v->variant != 9 ? 1 : 0;
-        if (label_ims && v->flat) {
-            dim3 grid((v->chunks_per_slice + 3) / 4, 1, nz);
-            if (mi.z_fastest) std::swap(grid.x, grid.z);
-            hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, true, true, false>), grid, block, 0, v->stream, mi);
-        } else if (label_ims) {
-            dim3 grid((mi.common.xgroups + 63) / 64, (c.dim_y + 3) / 4, nz);
-            if (mi.z_fastest) std::swap(grid.x, grid.z);
-            hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, true, false>), grid, block, 0, v->stream, mi);
-        } else {
+        {
             bool any_mask = false;
             for (int f = 0; f < n && masks_dev; ++f) any_mask = any_mask || masks_dev[f] != nullptr;
             dim3 grid_flat((v->chunks_per_slice + 3) / 4, 1, nz), grid_rows((mi.common.xgroups + 63) / 64, (c.dim_y + 3) / 4, nz);
@@ -620,6 +612,9 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
                 }
             }
             bool classify = tiles_fit(mi.common) && v->variant != 7;
+            // label launches classify only through bricks (a claimed wavefront-frame carries no label evidence either:
+            // skipped = not observed, free space = outside the truncation band)
+            if (label_ims && (mi.common.brick_q == 0 || v->variant == 11)) classify = false;
             if (classify && v->variant != 8 && v->variant != 11)
                 classify = !v->claims_known || v->claim_fraction >= 0.10 || v->launches_unclassified >= 7;
             v->launches_unclassified = classify ? 0 : v->launches_unclassified + 1;
@@ -651,7 +646,13 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
                 if (wgs > 65535u) mi.z_fastest = 0;   // the slow grid dimensions hold 65535 at most
                 grid_bricks = mi.z_fastest ? dim3((unsigned)nz, 1, wgs) : dim3(wgs, 1, (unsigned)nz);
             }
-            if (bricks && any_mask)
+            if (bricks && label_ims)
+                hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, true, false, true, true>), grid_bricks, block, 0, v->stream, mi);
+            else if (label_ims && v->flat)
+                hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, true, true, false>), grid_flat, block, 0, v->stream, mi);
+            else if (label_ims)
+                hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, true, false>), grid_rows, block, 0, v->stream, mi);
+            else if (bricks && any_mask)
                 hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, false, true, true, true>), grid_bricks, block, 0, v->stream, mi);
             else if (bricks)
                 hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, false, false, true, true>), grid_bricks, block, 0, v->stream, mi);

@@ -105,8 +105,9 @@ def test_config4_slab_of_2048_cube_with_labels(cuda, oracle):
     assert seen > 1000 and np.count_nonzero(lab) > 10000, (seen, int(np.count_nonzero(lab)))
 
 
+@pytest.mark.parametrize("variant", [0, 8, 7])   # classified through wavefront bricks: per launch / always / never
 @pytest.mark.parametrize("dims,n_frames", [((256, 40, 24), 7), ((200, 40, 24), 35)])   # row mapping; flat mapping across a pass boundary
-def test_fused_integrate_and_labels_equal_separate_passes(cuda, oracle, dims, n_frames):
+def test_fused_integrate_and_labels_equal_separate_passes(cuda, oracle, dims, n_frames, variant):
     """tsdf_integrate_frames_labels_device == tsdf_integrate_device + tsdf_integrate_labels_device per frame == the
     oracle's two functions, bit for bit, for the TSDF, the weights and the three label arrays."""
     vs = 2.0 / dims[0]
@@ -132,6 +133,7 @@ def test_fused_integrate_and_labels_equal_separate_passes(cuda, oracle, dims, n_
     keep = [(cuda.from_numpy(d).cuda(), cuda.from_numpy(l).cuda(), cuda.from_numpy(s_).cuda()) for _, d, l, s_ in frames]
     poses = np.stack([f[0] for f in frames])
     with capi.Volume(cfg) as vol:
+        vol.set_kernel_variant(variant)
         vol.labels_enable(0.5)
         vol.integrate_frames_labels_device([d.data_ptr() for d, _, _ in keep], [l.data_ptr() for _, l, _ in keep],
                                            [s_.data_ptr() for _, _, s_ in keep], poses)
