@@ -516,7 +516,7 @@ def main():
             def fblock(v, start, n):
                 return v.integrate_sequence_timed(f_dev.data_ptr(), Wf.block(start, n)[0])
             res = {}
-            for tag, var, nb in (("per_frame_launches", 3, 32), ("fused_classified", 0, 64), ("fused_per_voxel", 7, 64)):
+            for tag, var, nb in (("per_frame_launches", 3, 32), ("fused_classified", 0, 256), ("fused_per_voxel", 7, 128)):
                 fv.set_kernel_variant(var)
                 fv.reset()
                 fblock(fv, 0, 64)
