@@ -83,9 +83,15 @@ int tsdf_reset(tsdf_volume *vol);
  * metres, row-major, borrowed for the call only (copied to a pinned staging slot before
  * returning).  cam2world: current camera pose.  cam2base = inverse(base2world) * cam2world
  * is composed on the host in the reference's fp32 operation order (ref: src/tsdf.cu:142).
- * The kernel is queued on the handle's stream; the call does not wait for it.
+ * The call does not wait for the GPU.  DEFERRED INTEGRATION: the reference never reads a result back before its
+ * destructor (ref: src/tsdf.cu:101-104), so the frames of successive calls are collected in HBM and applied 32 at a
+ * time as one fused sequence (tsdf_integrate_frames_device: same results, bit for bit, several times the throughput);
+ * every entry point that observes or changes the volume -- sync, download, extraction, save, reset, any other integrate
+ * call -- first applies what has been collected.  tsdf_set_deferral(vol, 0) makes every call launch its own kernel.
  */
 int tsdf_integrate(tsdf_volume *vol, const float *depth_host, const float cam2world[16]);
+/* Frames tsdf_integrate collects per launch: 0 or 1 = none (one kernel per call), at most 32 (the default). */
+int tsdf_set_deferral(tsdf_volume *vol, int32_t n_frames);
 
 /*
  * Same from the sensor's raw 16-bit frame (TUM PNG payload): copies im_height*im_width uint16
@@ -395,9 +401,10 @@ int tsdf_batch_sync(tsdf_batch *batch);
  * device fields are ignored) into n_slabs contiguous z-slabs -- slab i holds z in [i*dim_z/n, (i+1)*dim_z/n) and lives
  * on devices[i], with its own stream; ordinals may repeat (several slabs on one device).  Needs n_slabs <= dim_z.
  *   tsdf_group_integrate         TSDF::Integrate for the whole grid (ref: src/tsdf.cu:135-168): the caller's frame is
- *                                copied once into pinned memory, fanned out with one asynchronous copy per slab on that
- *                                slab's stream and followed by its kernel; no synchronisation between devices and no
- *                                collective (voxels are independent); returns without waiting
+ *                                copied once into pinned memory; deferred like tsdf_integrate -- 32 collected frames go
+ *                                out as one copy and one fused launch per slab (tsdf_group_set_deferral(g, 0): one
+ *                                asynchronous copy per slab and its kernel per call); no synchronisation between
+ *                                devices and no collective (voxels are independent); returns without waiting
  *   tsdf_group_integrate_frames  a known sequence from host frames: per pass of up to 32 frames, one copy of the
  *                                frames to every device and one fused launch per slab (tsdf_integrate_frames_device)
  *   tsdf_group_download          the whole grid in z order (== one handle's tsdf_download, bit for bit)
@@ -418,6 +425,8 @@ int tsdf_group_volume(tsdf_group *group, int32_t i, tsdf_volume **vol);
 int tsdf_group_integrate(tsdf_group *group, const float *depth_host, const float cam2world[16]);
 int tsdf_group_integrate_frames(tsdf_group *group, const float *const *depth_host, const float *cam2world,
                                 int32_t n_frames);
+/* Frames tsdf_group_integrate collects per pass (deferred integration as for tsdf_integrate; default 32, 0 = none). */
+int tsdf_group_set_deferral(tsdf_group *group, int32_t n_frames);
 int tsdf_group_sync(tsdf_group *group);
 int tsdf_group_reset(tsdf_group *group);
 int tsdf_group_download(tsdf_group *group, float *tsdf_host, float *weight_host);

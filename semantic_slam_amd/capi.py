@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("TSDF_HIP_LIB") or os.path.join(_PKG, "libtsdf_hip.so"
 # every symbol include/tsdf_hip.h declares (tests check the .so exports exactly these)
 ABI_SYMBOLS = [
     "tsdf_config_default", "tsdf_create", "tsdf_destroy", "tsdf_reset", "tsdf_integrate",
-    "tsdf_integrate_u16", "tsdf_convert_depth_u16",
+    "tsdf_integrate_u16", "tsdf_convert_depth_u16", "tsdf_set_deferral",
     "tsdf_integrate_device", "tsdf_integrate_cam2base", "tsdf_integrate_masked_device",
     "tsdf_integrate_frames_device",
     "tsdf_sync", "tsdf_download", "tsdf_copy_slices", "tsdf_upload", "tsdf_refresh_summary", "tsdf_device_ptrs", "tsdf_slab_voxels", "tsdf_frames_per_launch", "tsdf_shortcut_stats", "tsdf_classification_info",
@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "tsdf_object_origin", "tsdf_batch_create", "tsdf_batch_destroy", "tsdf_batch_size", "tsdf_batch_volume",
     "tsdf_batch_integrate_device", "tsdf_batch_sync",
     "tsdf_group_create", "tsdf_group_destroy", "tsdf_group_size", "tsdf_group_voxels", "tsdf_group_volume",
-    "tsdf_group_integrate", "tsdf_group_integrate_frames", "tsdf_group_sync", "tsdf_group_reset", "tsdf_group_download",
+    "tsdf_group_integrate", "tsdf_group_integrate_frames", "tsdf_group_set_deferral", "tsdf_group_sync", "tsdf_group_reset", "tsdf_group_download",
     "tsdf_group_extract_surface", "tsdf_group_extract_crossings", "tsdf_group_extract_mesh",
     "tsdf_group_save_ply", "tsdf_group_save_mesh_ply", "tsdf_group_save_bin",
 ]
@@ -70,6 +70,7 @@ def load():
     L.tsdf_destroy.argtypes = [vp]
     L.tsdf_reset.argtypes = [vp]
     L.tsdf_integrate.argtypes = [vp, vp, vp]
+    L.tsdf_set_deferral.argtypes = [vp, C.c_int32]
     L.tsdf_integrate_u16.argtypes = [vp, vp, C.c_float, C.c_int32, C.c_int32, vp]
     L.tsdf_convert_depth_u16.argtypes = [vp, vp, vp, C.c_float, C.c_int32, C.c_int32]
     L.tsdf_integrate_device.argtypes = [vp, vp, vp]
@@ -138,6 +139,7 @@ def load():
     L.tsdf_group_volume.argtypes = [vp, C.c_int32, C.POINTER(vp)]
     L.tsdf_group_integrate.argtypes = [vp, vp, vp]
     L.tsdf_group_integrate_frames.argtypes = [vp, vp, vp, C.c_int32]
+    L.tsdf_group_set_deferral.argtypes = [vp, C.c_int32]
     L.tsdf_group_sync.argtypes = [vp]
     L.tsdf_group_reset.argtypes = [vp]
     L.tsdf_group_download.argtypes = [vp, vp, vp]
@@ -306,6 +308,10 @@ class Volume:
         d = _f32(depth_host, self.cfg.im_height * self.cfg.im_width)
         p = _f32(cam2world, 16)
         check(self.lib.tsdf_integrate(self._h, d.ctypes.data, p.ctypes.data), "tsdf_integrate")
+
+    def set_deferral(self, n_frames):
+        """Host frames collected per launch by integrate() (0 / 1: every call launches; default 32)."""
+        check(self.lib.tsdf_set_deferral(self._h, n_frames), "tsdf_set_deferral")
 
     def integrate_u16(self, raw_u16, cam2world, depth_factor=5000.0, row_step=1, col_step=1):
         """Raw 16-bit frame: half-size H2D copy, conversion (and optional subsampling) on the device."""
@@ -614,6 +620,9 @@ class Group:
         assert len(keep) == n
         ptrs = (C.c_void_p * n)(*[C.c_void_p(d.ctypes.data) for d in keep])
         check(self.lib.tsdf_group_integrate_frames(self._h, ptrs, p.ctypes.data, n), "tsdf_group_integrate_frames")
+
+    def set_deferral(self, n_frames):
+        check(self.lib.tsdf_group_set_deferral(self._h, n_frames), "tsdf_group_set_deferral")
 
     def sync(self):
         check(self.lib.tsdf_group_sync(self._h), "tsdf_group_sync")

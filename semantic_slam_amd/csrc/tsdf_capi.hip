@@ -74,6 +74,19 @@ struct tsdf_volume {
     // the H2D copy of a frame runs on its own stream and overlaps the previous frame's kernel; the kernel waits for it
     hipStream_t copy_stream;
     hipEvent_t copy_done[kStageSlots];
+    bool copy_used[kStageSlots];
+    // Deferred integration of host frames (tsdf_integrate): the reference reads results back only in its destructor
+    // (ref: src/tsdf.cu:101-104) and this library only at download / extraction / save, so the frames of successive
+    // calls are collected -- copied into a pool in HBM, poses composed at call time -- and applied defer_n at a time as
+    // ONE fused, classified sequence launch; every entry point that observes or changes the volume flushes first.
+    int defer_n;                      // frames per deferred launch (<= 1: every call launches; default kMaxFramesPerLaunch)
+    float *d_pool[2];                 // two pools of defer_n frames: one being filled, one being read by a launch
+    hipEvent_t pool_done[2];
+    bool pool_used[2];
+    hipEvent_t pend_copied;
+    int pool_cur, pend_count;
+    bool in_flush;
+    float pend_c2b[16 * tsdfk::kMaxFramesPerLaunch];
     int variant;
     // per-launch frame blocks of integrate_multi: pinned host ring -> device ring (allocated on first use)
     tsdfk::FramePose *h_frames[kStageSlots];
@@ -142,9 +155,14 @@ struct tsdf_batch {
 
 namespace {
 
-int bind_device(const tsdf_volume *v)
+int flush_pending(tsdf_volume *v);
+
+// Every entry point starts here: make the handle's device current and, unless the caller is the collecting call itself,
+// apply the host frames tsdf_integrate has collected (deferred integration, see struct tsdf_volume).
+int bind_device(tsdf_volume *v, bool flush = true)
 {
     HIP_TRY(hipSetDevice(v->cfg.device));
+    if (flush && v->pend_count > 0 && !v->in_flush) return flush_pending(v);
     return TSDF_OK;
 }
 
@@ -727,11 +745,16 @@ int frames_per_launch(const tsdf_volume *)
     return tsdfk::kMaxFramesPerLaunch;
 }
 
+bool can_fuse(const tsdf_volume *v)
+{
+    return (v->variant == 0 || (v->variant >= 4 && v->variant <= 11)) && v->cfg.dim_x % 4 == 0;
+}
+
 // A sequence of frames: fused frames_per_launch() at a time when the default kernel is selected.
 int integrate_frames(tsdf_volume *v, const float *const *depth_dev, const uint8_t *const *masks_dev,
                      const float *cam2world, int n_frames)
 {
-    const bool fuse = (v->variant == 0 || (v->variant >= 4 && v->variant <= 11)) && v->cfg.dim_x % 4 == 0;
+    const bool fuse = can_fuse(v);
     int rc = TSDF_OK;
     for (int k = 0; k < n_frames && rc == TSDF_OK;) {
         const int n = fuse ? std::min(frames_per_launch(v), n_frames - k) : 1;
@@ -741,6 +764,38 @@ int integrate_frames(tsdf_volume *v, const float *const *depth_dev, const uint8_
         else rc = launch_integrate(v, depth_dev[k], masks_dev ? masks_dev[k] : nullptr, c2b);
         k += n;
     }
+    return rc;
+}
+
+// Apply the collected host frames (poses already composed) as one sequence.
+int flush_pending(tsdf_volume *v)
+{
+    if (v->pend_count == 0 || v->in_flush) return TSDF_OK;
+    v->in_flush = true;
+    const int n = v->pend_count, p = v->pool_cur;
+    v->pend_count = 0;
+    v->pool_cur = p ^ 1;
+    const size_t px = (size_t)v->cfg.im_height * v->cfg.im_width;
+    int rc = TSDF_OK;
+    hipError_t e = hipSetDevice(v->cfg.device);
+    // the batch's copies ran in order on the copy stream: one event after the last of them covers all
+    if (e == hipSuccess) e = hipEventRecord(v->pend_copied, v->copy_stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(v->stream, v->pend_copied, 0);
+    if (e == hipSuccess) {
+        const float *ptrs[tsdfk::kMaxFramesPerLaunch];
+        for (int f = 0; f < n; ++f) ptrs[f] = v->d_pool[p] + (size_t)f * px;
+        if (can_fuse(v)) {
+            rc = launch_multi(v, ptrs, nullptr, v->pend_c2b, n);
+        } else {
+            for (int f = 0; f < n && rc == TSDF_OK; ++f) rc = launch_integrate(v, ptrs[f], nullptr, v->pend_c2b + 16 * f);
+        }
+        if (rc == TSDF_OK) {
+            e = hipEventRecord(v->pool_done[p], v->stream);
+            v->pool_used[p] = true;
+        }
+    }
+    v->in_flush = false;
+    if (e != hipSuccess) return fail(TSDF_ERR_HIP, "deferred integration: %s", hipGetErrorString(e));
     return rc;
 }
 
@@ -922,6 +977,7 @@ int tsdf_create(const tsdf_config *cfg, tsdf_volume **out)
     if ((e = hipStreamCreateWithFlags(&v->own_stream, hipStreamNonBlocking)) != hipSuccess)
         return cleanup(fail(TSDF_ERR_HIP, "tsdf_create: hipStreamCreate: %s", hipGetErrorString(e)));
     v->stream = v->own_stream;
+    v->defer_n = tsdfk::kMaxFramesPerLaunch;
     if ((e = hipStreamCreateWithFlags(&v->copy_stream, hipStreamNonBlocking)) != hipSuccess)
         return cleanup(fail(TSDF_ERR_HIP, "tsdf_create: hipStreamCreate: %s", hipGetErrorString(e)));
     size_t bytes = (size_t)(v->n_vox > 0 ? v->n_vox : 1) * sizeof(float);
@@ -954,6 +1010,12 @@ int tsdf_destroy(tsdf_volume *v)
     if (v->own_stream) (void)hipStreamSynchronize(v->own_stream);
     if (v->stream && v->stream != v->own_stream) (void)hipStreamSynchronize(v->stream);
     if (v->copy_stream) (void)hipStreamSynchronize(v->copy_stream);
+    v->pend_count = 0;   // frames collected but never observed: nothing can tell whether they were applied
+    for (int i = 0; i < 2; ++i) {
+        if (v->d_pool[i]) (void)hipFree(v->d_pool[i]);
+        if (v->pool_done[i]) (void)hipEventDestroy(v->pool_done[i]);
+    }
+    if (v->pend_copied) (void)hipEventDestroy(v->pend_copied);
     for (int i = 0; i < kStageSlots; ++i) {
         if (v->copy_done[i]) (void)hipEventDestroy(v->copy_done[i]);
         if (v->stage_done[i]) (void)hipEventDestroy(v->stage_done[i]);
@@ -1002,16 +1064,42 @@ int tsdf_reset(tsdf_volume *v)
 int tsdf_integrate(tsdf_volume *v, const float *depth_host, const float cam2world[16])
 {
     if (!v || !depth_host || !cam2world) return fail(TSDF_ERR_INVALID, "tsdf_integrate: NULL argument");
-    int rc = bind_device(v);
+    const bool defer = v->defer_n > 1;
+    int rc = bind_device(v, !defer);
     if (rc) return rc;
     const int s = v->stage_next;
     v->stage_next = (s + 1) % kStageSlots;
-    if (v->stage_used[s]) HIP_TRY(hipEventSynchronize(v->stage_done[s]));  // slot's last kernel done
-    size_t img = (size_t)v->cfg.im_height * v->cfg.im_width * sizeof(float);
+    // the pinned slot is free when its last copy has run (deferred calls) and its last kernel has (immediate calls)
+    if (v->copy_used[s]) HIP_TRY(hipEventSynchronize(v->copy_done[s]));
+    if (v->stage_used[s]) HIP_TRY(hipEventSynchronize(v->stage_done[s]));
+    const size_t px = (size_t)v->cfg.im_height * v->cfg.im_width, img = px * sizeof(float);
     std::memcpy(v->h_stage[s], depth_host, img);  // caller may free depth_host after we return
+    if (defer) {
+        // collect: frame into the pool being filled, pose composed now; launched defer_n at a time (or at the next
+        // call that observes the volume) as one fused sequence
+        const int p = v->pool_cur, slot = v->pend_count;
+        if (!v->d_pool[0]) {
+            for (int i = 0; i < 2; ++i) {
+                HIP_TRY(hipMalloc((void **)&v->d_pool[i], (size_t)tsdfk::kMaxFramesPerLaunch * img));
+                HIP_TRY(hipEventCreateWithFlags(&v->pool_done[i], hipEventDisableTiming));
+            }
+            HIP_TRY(hipEventCreateWithFlags(&v->pend_copied, hipEventDisableTiming));
+        }
+        // the launch that read this pool two batches ago must have finished before frames are copied over it
+        if (slot == 0 && v->pool_used[p]) HIP_TRY(hipStreamWaitEvent(v->copy_stream, v->pool_done[p], 0));
+        HIP_TRY(hipMemcpyAsync(v->d_pool[p] + (size_t)slot * px, v->h_stage[s], img, hipMemcpyHostToDevice, v->copy_stream));
+        HIP_TRY(hipEventRecord(v->copy_done[s], v->copy_stream));
+        v->copy_used[s] = true;
+        compose_cam2base(v, cam2world, v->pend_c2b + 16 * slot);
+        std::memcpy(v->last_cam2base, v->pend_c2b + 16 * slot, sizeof v->last_cam2base);
+        v->pend_count = slot + 1;
+        if (v->pend_count >= std::min(v->defer_n, (int)tsdfk::kMaxFramesPerLaunch)) return flush_pending(v);
+        return TSDF_OK;
+    }
     // copy on the copy stream (it overlaps the kernel of the previous frame), kernel after it
     HIP_TRY(hipMemcpyAsync(v->d_stage[s], v->h_stage[s], img, hipMemcpyHostToDevice, v->copy_stream));
     HIP_TRY(hipEventRecord(v->copy_done[s], v->copy_stream));
+    v->copy_used[s] = true;
     HIP_TRY(hipStreamWaitEvent(v->stream, v->copy_done[s], 0));
     float c2b[16];
     compose_cam2base(v, cam2world, c2b);
@@ -1019,6 +1107,17 @@ int tsdf_integrate(tsdf_volume *v, const float *depth_host, const float cam2worl
     if (rc) return rc;
     HIP_TRY(hipEventRecord(v->stage_done[s], v->stream));
     v->stage_used[s] = true;
+    return TSDF_OK;
+}
+
+int tsdf_set_deferral(tsdf_volume *v, int32_t n_frames)
+{
+    if (!v) return fail(TSDF_ERR_INVALID, "tsdf_set_deferral: NULL handle");
+    if (n_frames < 0 || n_frames > tsdfk::kMaxFramesPerLaunch)
+        return fail(TSDF_ERR_INVALID, "tsdf_set_deferral: n_frames must be in [0, %d]", tsdfk::kMaxFramesPerLaunch);
+    int rc = bind_device(v);   // applies what has been collected under the old setting
+    if (rc) return rc;
+    v->defer_n = n_frames;
     return TSDF_OK;
 }
 
@@ -1046,12 +1145,14 @@ int tsdf_integrate_u16(tsdf_volume *v, const uint16_t *raw_host, float depth_fac
     if (rc) return rc;
     const int s = v->stage_next;
     v->stage_next = (s + 1) % kStageSlots;
+    if (v->copy_used[s]) HIP_TRY(hipEventSynchronize(v->copy_done[s]));
     if (v->stage_used[s]) HIP_TRY(hipEventSynchronize(v->stage_done[s]));
     const size_t px = (size_t)v->cfg.im_height * v->cfg.im_width;
     if (!v->d_raw[s]) HIP_TRY(hipMalloc((void **)&v->d_raw[s], px * sizeof(uint16_t)));
     std::memcpy(v->h_stage[s], raw_host, px * sizeof(uint16_t));  // the float-sized pinned slot holds it
     HIP_TRY(hipMemcpyAsync(v->d_raw[s], v->h_stage[s], px * sizeof(uint16_t), hipMemcpyHostToDevice, v->copy_stream));
     HIP_TRY(hipEventRecord(v->copy_done[s], v->copy_stream));
+    v->copy_used[s] = true;
     HIP_TRY(hipStreamWaitEvent(v->stream, v->copy_done[s], 0));
     rc = tsdf_convert_depth_u16(v, v->d_raw[s], v->d_stage[s], depth_factor, row_step, col_step);
     if (rc) return rc;
@@ -1190,6 +1291,8 @@ int tsdf_refresh_summary(tsdf_volume *v)
 int tsdf_device_ptrs(tsdf_volume *v, float **tsdf_dev, float **weight_dev)
 {
     if (!v) return fail(TSDF_ERR_INVALID, "tsdf_device_ptrs: NULL handle");
+    int rc = bind_device(v);   // what the caller reads through the pointers must include every frame handed over so far
+    if (rc) return rc;
     if (tsdf_dev) *tsdf_dev = v->d_tsdf;
     if (weight_dev) *weight_dev = v->d_weight;
     return TSDF_OK;
@@ -1570,6 +1673,7 @@ int tsdf_integrate_rgbd(tsdf_volume *v, const float *depth_host, const uint8_t *
     if (rc) return rc;
     const int s = v->stage_next;
     v->stage_next = (s + 1) % kStageSlots;
+    if (v->copy_used[s]) HIP_TRY(hipEventSynchronize(v->copy_done[s]));
     if (v->stage_used[s]) HIP_TRY(hipEventSynchronize(v->stage_done[s]));
     const size_t px = (size_t)v->cfg.im_height * v->cfg.im_width, img = px * sizeof(float);
     if (!v->d_rgb[s]) {
@@ -1581,6 +1685,7 @@ int tsdf_integrate_rgbd(tsdf_volume *v, const float *depth_host, const uint8_t *
     HIP_TRY(hipMemcpyAsync(v->d_stage[s], v->h_stage[s], img, hipMemcpyHostToDevice, v->copy_stream));
     HIP_TRY(hipMemcpyAsync(v->d_rgb[s], v->h_rgb[s], px * 3, hipMemcpyHostToDevice, v->copy_stream));
     HIP_TRY(hipEventRecord(v->copy_done[s], v->copy_stream));
+    v->copy_used[s] = true;
     HIP_TRY(hipStreamWaitEvent(v->stream, v->copy_done[s], 0));
     float c2b[16];
     compose_cam2base(v, cam2world, c2b);
@@ -1713,6 +1818,7 @@ int tsdf_batch_integrate_device(tsdf_batch *b, const float *depth_dev, const uin
     const int n = (int)b->vols.size();
     for (int i = 0; i < n; ++i) {
         tsdf_volume *v = b->vols[i];
+        if (v->pend_count > 0) { int rc = flush_pending(v); if (rc) return rc; }   // frames given to a borrowed handle come first
         float c2b[16];
         compose_cam2base(v, cam2world, c2b);   // each object has its own base frame (ref: src/Object.cpp:23-29)
         std::memcpy(v->last_cam2base, c2b, sizeof c2b);

@@ -28,8 +28,12 @@ struct tsdf_group {
     int ring_next;
     float *h_pool;                        // kMaxFramesPerLaunch frames, allocated on first tsdf_group_integrate_frames
     std::vector<float *> d_pool;          // per slab: the same frames in its device's memory
-    std::vector<hipEvent_t> pool_done;    // per slab: its last launch that read d_pool (and copy that read h_pool)
+    std::vector<hipEvent_t> pool_done;    // per slab: the copy of its last pass out of h_pool has run
     std::vector<bool> pool_used;
+    // deferred integration (as tsdf_integrate on one handle): tsdf_group_integrate collects frames in h_pool and applies
+    // defer_n of them per pass as one fused launch per slab; every other group entry point flushes first
+    int defer_n, pend_count;
+    float pend_poses[16 * tsdfk::kMaxFramesPerLaunch];
     std::vector<float *> d_halo;          // per slab: slice z_end of the next slab (tsdf, then weight), on first use
 };
 
@@ -79,8 +83,12 @@ int fetch_halo(tsdf_group *g, int i, const float **ht, const float **hw)
 enum class ListKind { Surface, Crossings, Mesh };
 
 // count pass on every slab (concurrently), then -- when a destination is given -- the emit passes into the right offsets
+int group_flush(tsdf_group *g);
+
 int group_list(tsdf_group *g, ListKind kind, float weight_thresh, float *out_host, int64_t capacity, int64_t *count)
 {
+    int rc_flush = group_flush(g);
+    if (rc_flush) return rc_flush;
     const int n = (int)g->slabs.size();
     const size_t item = kind == ListKind::Mesh ? 9 : 3;
     std::vector<int64_t> cnt((size_t)n, 0);
@@ -109,6 +117,50 @@ int group_list(tsdf_group *g, ListKind kind, float weight_thresh, float *out_hos
         int64_t c = 0;
         return pass(i, out_host + (size_t)off[(size_t)i] * item, room, &c);
     });
+}
+
+// The first n frames of h_pool (already there) into every slab: one copy and one fused launch per slab.
+int group_pass_from_pool(tsdf_group *g, const float *cam2world, int n)
+{
+    const size_t px = (size_t)g->cfg.im_height * g->cfg.im_width, img = px * sizeof(float);
+    for (size_t i = 0; i < g->slabs.size(); ++i) {
+        tsdf_volume *v = g->slabs[i];
+        int rc0 = bind_device(v);
+        if (rc0) return rc0;
+        if (!g->d_pool[i]) {
+            HIP_TRY(hipMalloc((void **)&g->d_pool[i], (size_t)tsdfk::kMaxFramesPerLaunch * img));
+            HIP_TRY(hipEventCreateWithFlags(&g->pool_done[i], hipEventDisableTiming));
+        }
+        // on the slab's stream: ordered after the launch that read d_pool in the previous pass
+        HIP_TRY(hipMemcpyAsync(g->d_pool[i], g->h_pool, (size_t)n * img, hipMemcpyHostToDevice, v->stream));
+        HIP_TRY(hipEventRecord(g->pool_done[i], v->stream));
+        g->pool_used[i] = true;
+        const float *ptrs[tsdfk::kMaxFramesPerLaunch];
+        for (int f = 0; f < n; ++f) ptrs[f] = g->d_pool[i] + (size_t)f * px;
+        int rc = integrate_frames(v, ptrs, nullptr, cam2world, n);
+        if (rc) return rc;
+    }
+    return TSDF_OK;
+}
+
+// h_pool may be overwritten when every slab's copy out of it has run.
+int group_wait_pool(tsdf_group *g)
+{
+    for (size_t i = 0; i < g->slabs.size(); ++i) {
+        if (g->pool_used[i]) {
+            HIP_TRY(hipSetDevice(g->slabs[i]->cfg.device));
+            HIP_TRY(hipEventSynchronize(g->pool_done[i]));
+        }
+    }
+    return TSDF_OK;
+}
+
+int group_flush(tsdf_group *g)
+{
+    if (g->pend_count == 0) return TSDF_OK;
+    const int n = g->pend_count;
+    g->pend_count = 0;
+    return group_pass_from_pool(g, g->pend_poses, n);
 }
 
 }  // namespace
@@ -149,6 +201,8 @@ int tsdf_group_create(const tsdf_config *cfg, const int32_t *devices, int32_t n_
     g->cfg.device = devices[0];
     g->ring_next = 0;
     g->h_pool = nullptr;
+    g->defer_n = tsdfk::kMaxFramesPerLaunch;
+    g->pend_count = 0;
     for (int s = 0; s < kStageSlots; ++s) g->h_ring[s] = nullptr;
     auto cleanup = [&](int code) { const std::string keep = g_last_error; tsdf_group_destroy(g); g_last_error = keep; return code; };
     for (int i = 0; i < n_slabs; ++i) {
@@ -197,6 +251,8 @@ int64_t tsdf_group_voxels(const tsdf_group *g)
 int tsdf_group_volume(tsdf_group *g, int32_t i, tsdf_volume **vol)
 {
     if (!g || !vol || i < 0 || i >= (int)g->slabs.size()) return fail(TSDF_ERR_INVALID, "tsdf_group_volume: bad argument");
+    int rc = group_flush(g);       // whoever borrows a slab sees every frame handed to the group so far
+    if (rc) return rc;
     *vol = g->slabs[(size_t)i];
     return TSDF_OK;
 }
@@ -204,6 +260,16 @@ int tsdf_group_volume(tsdf_group *g, int32_t i, tsdf_volume **vol)
 int tsdf_group_integrate(tsdf_group *g, const float *depth_host, const float cam2world[16])
 {
     if (!g || !depth_host || !cam2world) return fail(TSDF_ERR_INVALID, "tsdf_group_integrate: NULL argument");
+    if (g->defer_n > 1) {
+        // deferred (see tsdf_integrate): the frame into the pinned pool, launched defer_n at a time as one fused sequence
+        const size_t px = (size_t)g->cfg.im_height * g->cfg.im_width, bytes = px * sizeof(float);
+        if (!g->h_pool) HIP_TRY(hipHostMalloc((void **)&g->h_pool, (size_t)tsdfk::kMaxFramesPerLaunch * bytes, hipHostMallocPortable));
+        if (g->pend_count == 0) { int rc = group_wait_pool(g); if (rc) return rc; }
+        std::memcpy(g->h_pool + (size_t)g->pend_count * px, depth_host, bytes);
+        std::memcpy(g->pend_poses + 16 * g->pend_count, cam2world, 16 * sizeof(float));
+        if (++g->pend_count >= std::min(g->defer_n, (int)tsdfk::kMaxFramesPerLaunch)) return group_flush(g);
+        return TSDF_OK;
+    }
     const int s = g->ring_next;
     g->ring_next = (s + 1) % kStageSlots;
     const size_t img = (size_t)g->cfg.im_height * g->cfg.im_width * sizeof(float);
@@ -216,7 +282,8 @@ int tsdf_group_integrate(tsdf_group *g, const float *depth_host, const float cam
     }
     std::memcpy(g->h_ring[s], depth_host, img);          // the caller may free depth_host after we return
     for (tsdf_volume *v : g->slabs) {
-        HIP_TRY(hipSetDevice(v->cfg.device));
+        int rc0 = bind_device(v);      // device current; frames given to a borrowed slab handle come first
+        if (rc0) return rc0;
         HIP_TRY(hipMemcpyAsync(v->d_stage[s], g->h_ring[s], img, hipMemcpyHostToDevice, v->copy_stream));
         HIP_TRY(hipEventRecord(v->copy_done[s], v->copy_stream));
         HIP_TRY(hipStreamWaitEvent(v->stream, v->copy_done[s], 0));
@@ -236,41 +303,38 @@ int tsdf_group_integrate_frames(tsdf_group *g, const float *const *depth_host, c
     if (!g || !depth_host || !cam2world || n_frames < 0) return fail(TSDF_ERR_INVALID, "tsdf_group_integrate_frames: bad argument");
     for (int k = 0; k < n_frames; ++k)
         if (!depth_host[k]) return fail(TSDF_ERR_INVALID, "tsdf_group_integrate_frames: depth_host[%d] is NULL", k);
+    int rc = group_flush(g);
+    if (rc) return rc;
     const size_t px = (size_t)g->cfg.im_height * g->cfg.im_width, img = px * sizeof(float);
     const int fpl = tsdfk::kMaxFramesPerLaunch;
     if (!g->h_pool) HIP_TRY(hipHostMalloc((void **)&g->h_pool, (size_t)fpl * img, hipHostMallocPortable));
     for (int k = 0; k < n_frames; k += fpl) {
         const int n = std::min(fpl, n_frames - k);
-        // the pool is reused per pass: wait until every slab's previous pass has consumed it
-        for (size_t i = 0; i < g->slabs.size(); ++i) {
-            if (g->pool_used[i]) {
-                HIP_TRY(hipSetDevice(g->slabs[i]->cfg.device));
-                HIP_TRY(hipEventSynchronize(g->pool_done[i]));
-            }
-        }
+        rc = group_wait_pool(g);     // the pool is reused per pass
+        if (rc) return rc;
         for (int f = 0; f < n; ++f) std::memcpy(g->h_pool + (size_t)f * px, depth_host[k + f], img);
-        for (size_t i = 0; i < g->slabs.size(); ++i) {
-            tsdf_volume *v = g->slabs[i];
-            HIP_TRY(hipSetDevice(v->cfg.device));
-            if (!g->d_pool[i]) {
-                HIP_TRY(hipMalloc((void **)&g->d_pool[i], (size_t)fpl * img));
-                HIP_TRY(hipEventCreateWithFlags(&g->pool_done[i], hipEventDisableTiming));
-            }
-            HIP_TRY(hipMemcpyAsync(g->d_pool[i], g->h_pool, (size_t)n * img, hipMemcpyHostToDevice, v->stream));
-            const float *ptrs[tsdfk::kMaxFramesPerLaunch];
-            for (int f = 0; f < n; ++f) ptrs[f] = g->d_pool[i] + (size_t)f * px;
-            int rc = integrate_frames(v, ptrs, nullptr, cam2world + 16 * (size_t)k, n);
-            if (rc) return rc;
-            HIP_TRY(hipEventRecord(g->pool_done[i], v->stream));
-            g->pool_used[i] = true;
-        }
+        rc = group_pass_from_pool(g, cam2world + 16 * (size_t)k, n);
+        if (rc) return rc;
     }
+    return TSDF_OK;
+}
+
+int tsdf_group_set_deferral(tsdf_group *g, int32_t n_frames)
+{
+    if (!g) return fail(TSDF_ERR_INVALID, "tsdf_group_set_deferral: NULL handle");
+    if (n_frames < 0 || n_frames > tsdfk::kMaxFramesPerLaunch)
+        return fail(TSDF_ERR_INVALID, "tsdf_group_set_deferral: n_frames must be in [0, %d]", tsdfk::kMaxFramesPerLaunch);
+    int rc = group_flush(g);
+    if (rc) return rc;
+    g->defer_n = n_frames;
     return TSDF_OK;
 }
 
 int tsdf_group_sync(tsdf_group *g)
 {
     if (!g) return fail(TSDF_ERR_INVALID, "tsdf_group_sync: NULL handle");
+    int rc0 = group_flush(g);
+    if (rc0) return rc0;
     for (tsdf_volume *v : g->slabs) {
         int rc = tsdf_sync(v);
         if (rc) return rc;
@@ -281,6 +345,8 @@ int tsdf_group_sync(tsdf_group *g)
 int tsdf_group_reset(tsdf_group *g)
 {
     if (!g) return fail(TSDF_ERR_INVALID, "tsdf_group_reset: NULL handle");
+    int rc0 = group_flush(g);
+    if (rc0) return rc0;
     for (tsdf_volume *v : g->slabs) {
         int rc = tsdf_reset(v);
         if (rc) return rc;
@@ -291,6 +357,8 @@ int tsdf_group_reset(tsdf_group *g)
 int tsdf_group_download(tsdf_group *g, float *tsdf_host, float *weight_host)
 {
     if (!g) return fail(TSDF_ERR_INVALID, "tsdf_group_download: NULL handle");
+    int rc0 = group_flush(g);
+    if (rc0) return rc0;
     const size_t slice = (size_t)g->cfg.dim_x * g->cfg.dim_y;
     return for_each_slab(g, [&](int i) -> int {
         tsdf_volume *v = g->slabs[(size_t)i];
