@@ -799,6 +799,36 @@ int flush_pending(tsdf_volume *v)
     return rc;
 }
 
+// Deferred integration, collecting side: the address in the pool being filled where the next host frame goes (copies into it
+// run on the copy stream) ...
+int pool_slot_begin(tsdf_volume *v, float **dst)
+{
+    const size_t px = (size_t)v->cfg.im_height * v->cfg.im_width, img = px * sizeof(float);
+    const int p = v->pool_cur, slot = v->pend_count;
+    if (!v->d_pool[0]) {
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(hipMalloc((void **)&v->d_pool[i], (size_t)tsdfk::kMaxFramesPerLaunch * img));
+            HIP_TRY(hipEventCreateWithFlags(&v->pool_done[i], hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventCreateWithFlags(&v->pend_copied, hipEventDisableTiming));
+    }
+    // the launch that read this pool two batches ago must have finished before frames are copied over it
+    if (slot == 0 && v->pool_used[p]) HIP_TRY(hipStreamWaitEvent(v->copy_stream, v->pool_done[p], 0));
+    *dst = v->d_pool[p] + (size_t)slot * px;
+    return TSDF_OK;
+}
+
+// ... and the frame's pose, composed now; the batch is launched when it is full.
+int pool_slot_commit(tsdf_volume *v, const float cam2world[16])
+{
+    const int slot = v->pend_count;
+    compose_cam2base(v, cam2world, v->pend_c2b + 16 * slot);
+    std::memcpy(v->last_cam2base, v->pend_c2b + 16 * slot, sizeof v->last_cam2base);
+    v->pend_count = slot + 1;
+    if (v->pend_count >= std::min(v->defer_n, (int)tsdfk::kMaxFramesPerLaunch)) return flush_pending(v);
+    return TSDF_OK;
+}
+
 int fill(tsdf_volume *v)
 {
     if (v->n_vox == 0) return TSDF_OK;
@@ -1077,24 +1107,13 @@ int tsdf_integrate(tsdf_volume *v, const float *depth_host, const float cam2worl
     if (defer) {
         // collect: frame into the pool being filled, pose composed now; launched defer_n at a time (or at the next
         // call that observes the volume) as one fused sequence
-        const int p = v->pool_cur, slot = v->pend_count;
-        if (!v->d_pool[0]) {
-            for (int i = 0; i < 2; ++i) {
-                HIP_TRY(hipMalloc((void **)&v->d_pool[i], (size_t)tsdfk::kMaxFramesPerLaunch * img));
-                HIP_TRY(hipEventCreateWithFlags(&v->pool_done[i], hipEventDisableTiming));
-            }
-            HIP_TRY(hipEventCreateWithFlags(&v->pend_copied, hipEventDisableTiming));
-        }
-        // the launch that read this pool two batches ago must have finished before frames are copied over it
-        if (slot == 0 && v->pool_used[p]) HIP_TRY(hipStreamWaitEvent(v->copy_stream, v->pool_done[p], 0));
-        HIP_TRY(hipMemcpyAsync(v->d_pool[p] + (size_t)slot * px, v->h_stage[s], img, hipMemcpyHostToDevice, v->copy_stream));
+        float *dst = nullptr;
+        rc = pool_slot_begin(v, &dst);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(dst, v->h_stage[s], img, hipMemcpyHostToDevice, v->copy_stream));
         HIP_TRY(hipEventRecord(v->copy_done[s], v->copy_stream));
         v->copy_used[s] = true;
-        compose_cam2base(v, cam2world, v->pend_c2b + 16 * slot);
-        std::memcpy(v->last_cam2base, v->pend_c2b + 16 * slot, sizeof v->last_cam2base);
-        v->pend_count = slot + 1;
-        if (v->pend_count >= std::min(v->defer_n, (int)tsdfk::kMaxFramesPerLaunch)) return flush_pending(v);
-        return TSDF_OK;
+        return pool_slot_commit(v, cam2world);
     }
     // copy on the copy stream (it overlaps the kernel of the previous frame), kernel after it
     HIP_TRY(hipMemcpyAsync(v->d_stage[s], v->h_stage[s], img, hipMemcpyHostToDevice, v->copy_stream));
@@ -1141,7 +1160,10 @@ int tsdf_integrate_u16(tsdf_volume *v, const uint16_t *raw_host, float depth_fac
                        int32_t col_step, const float cam2world[16])
 {
     if (!v || !raw_host || !cam2world) return fail(TSDF_ERR_INVALID, "tsdf_integrate_u16: NULL argument");
-    int rc = bind_device(v);
+    if (!(depth_factor > 0.0f) || row_step < 1 || col_step < 1)
+        return fail(TSDF_ERR_INVALID, "tsdf_integrate_u16: depth_factor must be > 0 and steps >= 1");
+    const bool defer = v->defer_n > 1;
+    int rc = bind_device(v, !defer);
     if (rc) return rc;
     const int s = v->stage_next;
     v->stage_next = (s + 1) % kStageSlots;
@@ -1151,6 +1173,19 @@ int tsdf_integrate_u16(tsdf_volume *v, const uint16_t *raw_host, float depth_fac
     if (!v->d_raw[s]) HIP_TRY(hipMalloc((void **)&v->d_raw[s], px * sizeof(uint16_t)));
     std::memcpy(v->h_stage[s], raw_host, px * sizeof(uint16_t));  // the float-sized pinned slot holds it
     HIP_TRY(hipMemcpyAsync(v->d_raw[s], v->h_stage[s], px * sizeof(uint16_t), hipMemcpyHostToDevice, v->copy_stream));
+    if (defer) {
+        // collected like tsdf_integrate's frames: converted on the copy stream straight into the pool slot
+        float *dst = nullptr;
+        rc = pool_slot_begin(v, &dst);
+        if (rc) return rc;
+        const int n = (int)px;
+        hipLaunchKernelGGL(tsdfk::depth_u16_to_f32, dim3((n + 255) / 256), dim3(256), 0, v->copy_stream, v->d_raw[s], dst,
+                           v->cfg.im_height, v->cfg.im_width, 1.0f / depth_factor, row_step, col_step);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(v->copy_done[s], v->copy_stream));   // covers the copy and the conversion that read d_raw[s]
+        v->copy_used[s] = true;
+        return pool_slot_commit(v, cam2world);
+    }
     HIP_TRY(hipEventRecord(v->copy_done[s], v->copy_stream));
     v->copy_used[s] = true;
     HIP_TRY(hipStreamWaitEvent(v->stream, v->copy_done[s], 0));
