@@ -108,7 +108,12 @@ int tsdf_integrate_u16(tsdf_volume *vol, const uint16_t *raw_host, float depth_f
 int tsdf_convert_depth_u16(tsdf_volume *vol, const uint16_t *raw_dev, float *depth_dev, float depth_factor,
                            int32_t row_step, int32_t col_step);
 
-/* Same, with the depth frame already resident in HBM on the handle's device (no copy). */
+/*
+ * Same, with the depth frame already resident in HBM on the handle's device.  Deferred like tsdf_integrate: the frame is
+ * copied device to device into the collecting pool on the handle's stream (the ordering its kernel would have had), so
+ * depth_dev may be reused under that stream's order as before; with deferral off the kernel reads depth_dev itself.
+ * tsdf_integrate_cam2base and tsdf_integrate_masked_device (mask copied with the frame) are collected the same way.
+ */
 int tsdf_integrate_device(tsdf_volume *vol, const float *depth_dev, const float cam2world[16]);
 
 /*

@@ -87,6 +87,8 @@ struct tsdf_volume {
     int pool_cur, pend_count;
     bool in_flush;
     float pend_c2b[16 * tsdfk::kMaxFramesPerLaunch];
+    uint8_t *d_mask_pool[2];          // instance masks of collected masked frames (allocated on first use)
+    const uint8_t *pend_mask[tsdfk::kMaxFramesPerLaunch];
     int variant;
     // per-launch frame blocks of integrate_multi: pinned host ring -> device ring (allocated on first use)
     tsdfk::FramePose *h_frames[kStageSlots];
@@ -783,11 +785,15 @@ int flush_pending(tsdf_volume *v)
     if (e == hipSuccess) e = hipStreamWaitEvent(v->stream, v->pend_copied, 0);
     if (e == hipSuccess) {
         const float *ptrs[tsdfk::kMaxFramesPerLaunch];
-        for (int f = 0; f < n; ++f) ptrs[f] = v->d_pool[p] + (size_t)f * px;
-        if (can_fuse(v)) {
-            rc = launch_multi(v, ptrs, nullptr, v->pend_c2b, n);
-        } else {
-            for (int f = 0; f < n && rc == TSDF_OK; ++f) rc = launch_integrate(v, ptrs[f], nullptr, v->pend_c2b + 16 * f);
+        bool any_mask = false;
+        for (int f = 0; f < n; ++f) {
+            ptrs[f] = v->d_pool[p] + (size_t)f * px;
+            any_mask = any_mask || v->pend_mask[f] != nullptr;
+        }
+        if (can_fuse(v) && n > 1) {
+            rc = launch_multi(v, ptrs, any_mask ? v->pend_mask : nullptr, v->pend_c2b, n);
+        } else {   // a single collected frame (or a variant that does not fuse): the one-frame kernels
+            for (int f = 0; f < n && rc == TSDF_OK; ++f) rc = launch_integrate(v, ptrs[f], v->pend_mask[f], v->pend_c2b + 16 * f);
         }
         if (rc == TSDF_OK) {
             e = hipEventRecord(v->pool_done[p], v->stream);
@@ -818,15 +824,39 @@ int pool_slot_begin(tsdf_volume *v, float **dst)
     return TSDF_OK;
 }
 
-// ... and the frame's pose, composed now; the batch is launched when it is full.
-int pool_slot_commit(tsdf_volume *v, const float cam2world[16])
+// ... and the frame's pose, composed now (or given as the relative pose itself); the batch is launched when it is full.
+int pool_slot_commit(tsdf_volume *v, const float cam2world[16], const float *cam2base = nullptr, const uint8_t *mask = nullptr)
 {
     const int slot = v->pend_count;
-    compose_cam2base(v, cam2world, v->pend_c2b + 16 * slot);
+    if (cam2base) std::memcpy(v->pend_c2b + 16 * slot, cam2base, 16 * sizeof(float));
+    else compose_cam2base(v, cam2world, v->pend_c2b + 16 * slot);
+    v->pend_mask[slot] = mask;
     std::memcpy(v->last_cam2base, v->pend_c2b + 16 * slot, sizeof v->last_cam2base);
     v->pend_count = slot + 1;
     if (v->pend_count >= std::min(v->defer_n, (int)tsdfk::kMaxFramesPerLaunch)) return flush_pending(v);
     return TSDF_OK;
+}
+
+// A device-resident frame (and its instance mask) collected like a host frame: copied device to device into the pool on the
+// handle's stream -- the same ordering the frame's kernel would have had -- so the caller's buffer is free for reuse under
+// the stream's order, as before.
+int collect_device_frame(tsdf_volume *v, const float *depth_dev, const uint8_t *mask_dev, const float *cam2world,
+                         const float *cam2base)
+{
+    const size_t px = (size_t)v->cfg.im_height * v->cfg.im_width;
+    float *dst = nullptr;
+    int rc = pool_slot_begin(v, &dst);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(dst, depth_dev, px * sizeof(float), hipMemcpyDeviceToDevice, v->stream));
+    const uint8_t *mask = nullptr;
+    if (mask_dev) {
+        const int p = v->pool_cur;
+        if (!v->d_mask_pool[p]) HIP_TRY(hipMalloc((void **)&v->d_mask_pool[p], (size_t)tsdfk::kMaxFramesPerLaunch * px));
+        uint8_t *m = v->d_mask_pool[p] + (size_t)v->pend_count * px;
+        HIP_TRY(hipMemcpyAsync(m, mask_dev, px, hipMemcpyDeviceToDevice, v->stream));
+        mask = m;
+    }
+    return pool_slot_commit(v, cam2world, cam2base, mask);
 }
 
 int fill(tsdf_volume *v)
@@ -1043,6 +1073,7 @@ int tsdf_destroy(tsdf_volume *v)
     v->pend_count = 0;   // frames collected but never observed: nothing can tell whether they were applied
     for (int i = 0; i < 2; ++i) {
         if (v->d_pool[i]) (void)hipFree(v->d_pool[i]);
+        if (v->d_mask_pool[i]) (void)hipFree(v->d_mask_pool[i]);
         if (v->pool_done[i]) (void)hipEventDestroy(v->pool_done[i]);
     }
     if (v->pend_copied) (void)hipEventDestroy(v->pend_copied);
@@ -1203,8 +1234,10 @@ int tsdf_integrate_u16(tsdf_volume *v, const uint16_t *raw_host, float depth_fac
 int tsdf_integrate_device(tsdf_volume *v, const float *depth_dev, const float cam2world[16])
 {
     if (!v || !depth_dev || !cam2world) return fail(TSDF_ERR_INVALID, "tsdf_integrate_device: NULL argument");
-    int rc = bind_device(v);
+    const bool defer = v->defer_n > 1 && can_fuse(v);
+    int rc = bind_device(v, !defer);
     if (rc) return rc;
+    if (defer) return collect_device_frame(v, depth_dev, nullptr, cam2world, nullptr);
     float c2b[16];
     compose_cam2base(v, cam2world, c2b);
     return launch_integrate(v, depth_dev, nullptr, c2b);
@@ -1213,8 +1246,10 @@ int tsdf_integrate_device(tsdf_volume *v, const float *depth_dev, const float ca
 int tsdf_integrate_cam2base(tsdf_volume *v, const float *depth_dev, const float cam2base[16])
 {
     if (!v || !depth_dev || !cam2base) return fail(TSDF_ERR_INVALID, "tsdf_integrate_cam2base: NULL argument");
-    int rc = bind_device(v);
+    const bool defer = v->defer_n > 1 && can_fuse(v);
+    int rc = bind_device(v, !defer);
     if (rc) return rc;
+    if (defer) return collect_device_frame(v, depth_dev, nullptr, nullptr, cam2base);
     return launch_integrate(v, depth_dev, nullptr, cam2base);
 }
 
@@ -1256,8 +1291,10 @@ int tsdf_integrate_masked_device(tsdf_volume *v, const float *depth_dev, const u
 {
     if (!v || !depth_dev || !mask_dev || !cam2world)
         return fail(TSDF_ERR_INVALID, "tsdf_integrate_masked_device: NULL argument");
-    int rc = bind_device(v);
+    const bool defer = v->defer_n > 1 && can_fuse(v);
+    int rc = bind_device(v, !defer);
     if (rc) return rc;
+    if (defer) return collect_device_frame(v, depth_dev, mask_dev, cam2world, nullptr);
     float c2b[16];
     compose_cam2base(v, cam2world, c2b);
     return launch_integrate(v, depth_dev, mask_dev, c2b);

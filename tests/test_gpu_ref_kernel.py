@@ -60,7 +60,7 @@ def test_reference_kernel_on_device_reproduces_golden_and_product(cuda, oracle, 
         oracle.integrate(g.K, c2b, depth, g.dims, g.origin, g.vs, g.trunc, ot, ow)
     assert np.array_equal(ow, rw) and np.array_equal(ot.view(np.uint32), rt.view(np.uint32))
     # the product: default per-frame kernel and the fused sequence path
-    for variant, fused in ((0, False), (0, True), (8, True)):
+    for variant, fused in ((3, False), (0, False), (0, True), (8, True)):   # 3: one kernel per frame; 0: collected
         pt, pw = _product_run(cuda, g.K, g.frames, g.dims, g.origin, g.vs, g.trunc, h, w, variant, fused)
         assert np.array_equal(pw, rw), (variant, fused)
         assert np.array_equal(pt.view(np.uint32), rt.view(np.uint32)), (variant, fused)
@@ -91,7 +91,7 @@ def test_reference_kernel_oracle_and_product_agree_on_random_inputs(cuda, oracle
         oracle.integrate(K, c2b, depth, dims, origin, vs, trunc, ot, ow, threads=4)
     assert rw.sum() > 0
     assert np.array_equal(ow, rw) and np.array_equal(ot.view(np.uint32), rt.view(np.uint32))
-    for variant, fused in ((0, False), (0, True), (8, True), (2, False)):
+    for variant, fused in ((3, False), (0, False), (0, True), (8, True), (2, False)):
         pt, pw = _product_run(cuda, K, frames, dims, origin, vs, trunc, h, w, variant, fused)
         assert np.array_equal(pw, rw), (variant, fused)
         assert np.array_equal(pt.view(np.uint32), rt.view(np.uint32)), (variant, fused)
