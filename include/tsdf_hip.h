@@ -280,6 +280,14 @@ int tsdf_integrate_frames_timed(tsdf_volume *vol, const float *const *depth_dev,
                                 const float *cam2world, int32_t n_frames, float *elapsed_ms);
 
 /*
+ * Measurement aid: n_frames one-frame launches (one resident depth frame, poses cam2world[k*16..]) queued call by call
+ * against the same launches replayed from a captured hipGraph, iters repetitions each; device milliseconds per
+ * repetition.  Applies 2 * iters * n_frames (+ warm-up) frames to the volume.  (small grids.)
+ */
+int tsdf_probe_graph_replay(tsdf_volume *vol, const float *depth_dev, const float *cam2world, int32_t n_frames,
+                            int32_t iters, float *ms_launches, float *ms_graph);
+
+/*
  * Ceiling probe: n_iters passes of a bare 16 B/voxel read-modify-write stream over the slab
  * (values unchanged), timed with HIP events.  non_temporal selects nt loads/stores.
  */

@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "tsdf_sync", "tsdf_download", "tsdf_copy_slices", "tsdf_upload", "tsdf_refresh_summary", "tsdf_device_ptrs", "tsdf_slab_voxels", "tsdf_frames_per_launch", "tsdf_shortcut_stats", "tsdf_classification_info",
     "tsdf_get_config", "tsdf_last_cam2base", "tsdf_set_stream", "tsdf_get_stream",
     "tsdf_count_surface", "tsdf_extract_surface", "tsdf_extract_crossings", "tsdf_extract_mesh", "tsdf_save_mesh_ply", "tsdf_save_ply", "tsdf_save_bin", "tsdf_load_bin", "tsdf_save_state", "tsdf_load_state",
-    "tsdf_integrate_sequence_timed", "tsdf_integrate_frames_timed", "tsdf_probe_stream", "tsdf_selftest_fastdiv", "tsdf_selftest_fastdiv_band", "tsdf_selftest_round", "tsdf_set_kernel_variant", "tsdf_last_error",
+    "tsdf_integrate_sequence_timed", "tsdf_integrate_frames_timed", "tsdf_probe_graph_replay", "tsdf_probe_stream", "tsdf_selftest_fastdiv", "tsdf_selftest_fastdiv_band", "tsdf_selftest_round", "tsdf_set_kernel_variant", "tsdf_last_error",
     "tsdf_version", "tsdf_multiply_matrix", "tsdf_invert_matrix",
     "tsdf_labels_enable", "tsdf_compose_labels", "tsdf_integrate_labels_device", "tsdf_integrate_frames_labels_device",
     "tsdf_download_labels",
@@ -105,6 +105,7 @@ def load():
     L.tsdf_load_state.argtypes = [vp, C.c_char_p]
     L.tsdf_integrate_sequence_timed.argtypes = [vp, vp, vp, C.c_int32, f32p]
     L.tsdf_integrate_frames_timed.argtypes = [vp, vp, vp, vp, C.c_int32, f32p]
+    L.tsdf_probe_graph_replay.argtypes = [vp, vp, vp, C.c_int32, C.c_int32, f32p, f32p]
     L.tsdf_probe_stream.argtypes = [vp, C.c_int32, C.c_int32, f32p]
     L.tsdf_selftest_fastdiv.argtypes = [C.c_int32, C.c_uint64, C.c_uint64, C.c_float, C.c_float, C.POINTER(C.c_uint64), f32p]
     L.tsdf_selftest_fastdiv_band.argtypes = [C.c_int32, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), f32p]
@@ -372,6 +373,14 @@ class Volume:
         check(self.lib.tsdf_integrate_frames_timed(self._h, d, m, p.ctypes.data, n, C.byref(ms)),
               "tsdf_integrate_frames_timed")
         return ms.value
+
+    def probe_graph_replay(self, depth_ptr, poses, iters=20):
+        """(ms per repetition queued call by call, ms per repetition replayed from a captured hipGraph)."""
+        p = _f32(np.asarray(poses, dtype=np.float32))
+        a, b = C.c_float(), C.c_float()
+        check(self.lib.tsdf_probe_graph_replay(self._h, depth_ptr, p.ctypes.data, p.size // 16, iters, C.byref(a), C.byref(b)),
+              "tsdf_probe_graph_replay")
+        return a.value, b.value
 
     def probe_stream(self, non_temporal=False, iters=20):
         """Bare RMW stream over the slab (ceiling probe); returns milliseconds per pass."""

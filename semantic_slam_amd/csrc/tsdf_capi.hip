@@ -1611,6 +1611,59 @@ int tsdf_integrate_sequence_timed(tsdf_volume *v, const float *depth_dev, const 
     return frames_timed(v, depths.data(), nullptr, cam2world, n_frames, elapsed_ms, "tsdf_integrate_sequence_timed");
 }
 
+// Measurement aid ("hipGraph"): the same n one-frame launches queued call by call and replayed from a
+// captured hipGraph, `iters` times each; device milliseconds per repetition by HIP events.  The volume ends up with
+// 2 * iters * n more frames applied than before (both forms run).
+int tsdf_probe_graph_replay(tsdf_volume *v, const float *depth_dev, const float *cam2world, int32_t n_frames, int32_t iters,
+                            float *ms_launches, float *ms_graph)
+{
+    if (!v || !depth_dev || !cam2world || n_frames <= 0 || iters <= 0 || !ms_launches || !ms_graph)
+        return fail(TSDF_ERR_INVALID, "tsdf_probe_graph_replay: bad argument");
+    int rc = bind_device(v);
+    if (rc) return rc;
+    std::vector<float> c2b((size_t)n_frames * 16);
+    for (int k = 0; k < n_frames; ++k) compose_cam2base(v, cam2world + 16 * k, c2b.data() + 16 * k);
+    auto queue_all = [&]() -> int {
+        for (int k = 0; k < n_frames; ++k) {
+            int r = launch_integrate(v, depth_dev, nullptr, c2b.data() + 16 * k);
+            if (r) return r;
+        }
+        return TSDF_OK;
+    };
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    rc = queue_all();                                   // warm-up (and the summary's one-off work)
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(e0, v->stream));
+    for (int i = 0; i < iters && rc == TSDF_OK; ++i) rc = queue_all();
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(e1, v->stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    HIP_TRY(hipEventElapsedTime(ms_launches, e0, e1));
+    *ms_launches /= (float)iters;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    HIP_TRY(hipStreamBeginCapture(v->stream, hipStreamCaptureModeThreadLocal));
+    rc = queue_all();
+    hipError_t ce = hipStreamEndCapture(v->stream, &graph);
+    if (rc) return rc;
+    if (ce != hipSuccess) return fail(TSDF_ERR_HIP, "tsdf_probe_graph_replay: capture failed: %s", hipGetErrorString(ce));
+    HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    HIP_TRY(hipGraphLaunch(exec, v->stream));           // warm-up
+    HIP_TRY(hipEventRecord(e0, v->stream));
+    for (int i = 0; i < iters; ++i) HIP_TRY(hipGraphLaunch(exec, v->stream));
+    HIP_TRY(hipEventRecord(e1, v->stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    HIP_TRY(hipEventElapsedTime(ms_graph, e0, e1));
+    *ms_graph /= (float)iters;
+    (void)hipGraphExecDestroy(exec);
+    (void)hipGraphDestroy(graph);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return TSDF_OK;
+}
+
 int tsdf_integrate_frames_timed(tsdf_volume *v, const float *const *depth_dev, const uint8_t *const *masks_dev,
                                 const float *cam2world, int32_t n_frames, float *elapsed_ms)
 {
