@@ -240,6 +240,13 @@ int tsdf_extract_crossings(tsdf_volume *vol, const float *halo_tsdf, const float
 int tsdf_extract_mesh(tsdf_volume *vol, const float *halo_tsdf, const float *halo_weight, float weight_thresh,
                       float *triangles_host, int64_t capacity, int64_t *count);
 int tsdf_save_mesh_ply(tsdf_volume *vol, const char *path, float weight_thresh);
+/*
+ * The same mesh as the reference's Python glue saves it (ref: src/TSDFfusion.py.in:48-53, get_mesh -> verts, faces,
+ * norms, colors -> meshwrite): shared (welded) vertices -- the soup's edge vertices are bit-identical between cubes, so
+ * welding matches coordinate bits exactly --, an area-weighted normal per vertex, a colour per vertex when colour is
+ * enabled, faces as vertex indices in the soup's order and winding.  Binary little-endian .ply.
+ */
+int tsdf_save_mesh_welded_ply(tsdf_volume *vol, const char *path, float weight_thresh);
 
 /*
  * File writers, byte-compatible with the reference's destructor (ref: src/tsdf.cu:107-132,

@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "tsdf_integrate_frames_device",
     "tsdf_sync", "tsdf_download", "tsdf_copy_slices", "tsdf_upload", "tsdf_refresh_summary", "tsdf_device_ptrs", "tsdf_slab_voxels", "tsdf_frames_per_launch", "tsdf_shortcut_stats", "tsdf_classification_info",
     "tsdf_get_config", "tsdf_last_cam2base", "tsdf_set_stream", "tsdf_get_stream",
-    "tsdf_count_surface", "tsdf_extract_surface", "tsdf_extract_crossings", "tsdf_extract_mesh", "tsdf_save_mesh_ply", "tsdf_save_ply", "tsdf_save_bin", "tsdf_load_bin", "tsdf_save_state", "tsdf_load_state",
+    "tsdf_count_surface", "tsdf_extract_surface", "tsdf_extract_crossings", "tsdf_extract_mesh", "tsdf_save_mesh_ply", "tsdf_save_mesh_welded_ply", "tsdf_save_ply", "tsdf_save_bin", "tsdf_load_bin", "tsdf_save_state", "tsdf_load_state",
     "tsdf_integrate_sequence_timed", "tsdf_integrate_frames_timed", "tsdf_probe_graph_replay", "tsdf_probe_stream", "tsdf_selftest_fastdiv", "tsdf_selftest_fastdiv_band", "tsdf_selftest_round", "tsdf_set_kernel_variant", "tsdf_last_error",
     "tsdf_version", "tsdf_multiply_matrix", "tsdf_invert_matrix",
     "tsdf_labels_enable", "tsdf_compose_labels", "tsdf_integrate_labels_device", "tsdf_integrate_frames_labels_device",
@@ -98,6 +98,7 @@ def load():
     L.tsdf_extract_crossings.argtypes = [vp, vp, vp, C.c_float, vp, C.c_int64, i64p]
     L.tsdf_extract_mesh.argtypes = [vp, vp, vp, C.c_float, vp, C.c_int64, i64p]
     L.tsdf_save_mesh_ply.argtypes = [vp, C.c_char_p, C.c_float]
+    L.tsdf_save_mesh_welded_ply.argtypes = [vp, C.c_char_p, C.c_float]
     L.tsdf_save_ply.argtypes = [vp, C.c_char_p, C.c_float]
     L.tsdf_save_bin.argtypes = [vp, C.c_char_p]
     L.tsdf_load_bin.argtypes = [vp, C.c_char_p]
@@ -538,6 +539,9 @@ class Volume:
 
     def save_mesh_ply(self, path, weight_thresh=0.9):
         check(self.lib.tsdf_save_mesh_ply(self._h, os.fsencode(path), weight_thresh), "tsdf_save_mesh_ply")
+
+    def save_mesh_welded_ply(self, path, weight_thresh=0.9):
+        check(self.lib.tsdf_save_mesh_welded_ply(self._h, os.fsencode(path), weight_thresh), "tsdf_save_mesh_welded_ply")
 
     def save_ply(self, path, weight_thresh=0.9):
         check(self.lib.tsdf_save_ply(self._h, os.fsencode(path), weight_thresh), "tsdf_save_ply")

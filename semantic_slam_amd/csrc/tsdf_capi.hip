@@ -19,6 +19,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "pose_math.h"
@@ -2188,6 +2189,87 @@ int tsdf_save_mesh_ply(tsdf_volume *v, const char *path, float weight_thresh)
         return write_mesh_ply(path, tri.data(), n, "tsdf_save_mesh_ply", rgb.data());
     }
     return write_mesh_ply(path, tri.data(), n, "tsdf_save_mesh_ply");
+}
+
+// The mesh as the reference's Python glue saves it (ref: src/TSDFfusion.py.in:48-53: get_mesh -> verts, faces, norms,
+// colors -> meshwrite): shared vertices, a normal per vertex, a colour per vertex when colour is enabled.  The triangle soup's
+// edge vertices are bit-identical between neighbouring cubes (tsdf_extract.hip.h), so welding is an exact match on the three
+// coordinates' bits; normals are the area-weighted sums of the face normals; faces keep the soup's order and winding.
+int tsdf_save_mesh_welded_ply(tsdf_volume *v, const char *path, float weight_thresh)
+{
+    if (!v || !path) return fail(TSDF_ERR_INVALID, "tsdf_save_mesh_welded_ply: NULL argument");
+    int64_t n = 0;
+    int rc = crossing_pass(v, nullptr, nullptr, weight_thresh, nullptr, 0, &n, true);
+    if (rc) return rc;
+    if (3 * n > 0x7fffffffll) return fail(TSDF_ERR_INVALID, "tsdf_save_mesh_welded_ply: %lld triangles exceed 32-bit vertex indices", (long long)n);
+    std::vector<float> tri((size_t)(n > 0 ? n : 1) * 9);
+    if (n > 0 && (rc = crossing_pass(v, nullptr, nullptr, weight_thresh, tri.data(), n, &n, true)) != TSDF_OK) return rc;
+    struct Key { uint32_t x, y, z; bool operator==(const Key &o) const { return x == o.x && y == o.y && z == o.z; } };
+    struct Hash { size_t operator()(const Key &k) const { uint64_t h = k.x * 0x9E3779B97F4A7C15ull; h ^= (h >> 29) + k.y * 0xBF58476D1CE4E5B9ull; h ^= (h >> 31) + k.z * 0x94D049BB133111EBull; return (size_t)(h ^ (h >> 32)); } };
+    std::unordered_map<Key, int32_t, Hash> ids;
+    ids.reserve((size_t)n);
+    std::vector<float> verts;
+    std::vector<int32_t> faces((size_t)(n > 0 ? n : 1) * 3);
+    for (int64_t k = 0; k < 3 * n; ++k) {
+        Key key;
+        std::memcpy(&key, tri.data() + 3 * k, 12);
+        auto it = ids.find(key);
+        if (it == ids.end()) {
+            it = ids.emplace(key, (int32_t)(verts.size() / 3)).first;
+            verts.insert(verts.end(), tri.data() + 3 * k, tri.data() + 3 * k + 3);
+        }
+        faces[(size_t)k] = it->second;
+    }
+    const size_t nv = verts.size() / 3;
+    std::vector<double> acc(nv * 3 + 3, 0.0);
+    for (int64_t f = 0; f < n; ++f) {
+        const float *a = tri.data() + 9 * f, *b = a + 3, *c = a + 6;
+        const double ux = (double)b[0] - a[0], uy = (double)b[1] - a[1], uz = (double)b[2] - a[2];
+        const double wx = (double)c[0] - a[0], wy = (double)c[1] - a[1], wz = (double)c[2] - a[2];
+        const double nx = uy * wz - uz * wy, ny = uz * wx - ux * wz, nz = ux * wy - uy * wx;   // 2 x area x unit normal
+        for (int k = 0; k < 3; ++k) { double *q = acc.data() + 3 * (size_t)faces[(size_t)(3 * f + k)]; q[0] += nx; q[1] += ny; q[2] += nz; }
+    }
+    std::vector<uint32_t> col;
+    if (v->d_colour) {
+        col.resize((size_t)(v->n_vox > 0 ? v->n_vox : 1));
+        rc = tsdf_download_colour(v, col.data());
+        if (rc) return rc;
+    }
+    const tsdf_config &c = v->cfg;
+    const int nz_ = c.z_end - c.z_begin;
+    const size_t rec_bytes = 24 + (v->d_colour ? 3 : 0);
+    std::vector<unsigned char> rec((nv > 0 ? nv : 1) * rec_bytes);
+    for (size_t i = 0; i < nv; ++i) {
+        const float *p = verts.data() + 3 * i;
+        const double *q = acc.data() + 3 * i;
+        const double len = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+        const float nrm[3] = {len > 0 ? (float)(q[0] / len) : 0.0f, len > 0 ? (float)(q[1] / len) : 0.0f, len > 0 ? (float)(q[2] / len) : 0.0f};
+        unsigned char *r = rec.data() + i * rec_bytes;
+        std::memcpy(r, p, 12);
+        std::memcpy(r + 12, nrm, 12);
+        if (v->d_colour) {   // the nearest voxel's colour (the Python glue indexes its colour volume with the rounded vertex)
+            long ix = std::lround((p[0] - c.origin[0]) / c.voxel_size), iy = std::lround((p[1] - c.origin[1]) / c.voxel_size);
+            long iz = std::lround((p[2] - c.origin[2]) / c.voxel_size) - c.z_begin;
+            ix = std::min<long>(std::max<long>(ix, 0), c.dim_x - 1);
+            iy = std::min<long>(std::max<long>(iy, 0), c.dim_y - 1);
+            iz = std::min<long>(std::max<long>(iz, 0), nz_ - 1);
+            const uint32_t u = col[((size_t)iz * c.dim_y + (size_t)iy) * c.dim_x + (size_t)ix];
+            r[24] = (unsigned char)(u & 255u); r[25] = (unsigned char)((u >> 8) & 255u); r[26] = (unsigned char)((u >> 16) & 255u);
+        }
+    }
+    FILE *fp = std::fopen(path, "wb");
+    if (!fp) return fail(TSDF_ERR_IO, "tsdf_save_mesh_welded_ply: cannot open %s", path);
+    std::fprintf(fp, "ply\nformat binary_little_endian 1.0\nelement vertex %zu\n", nv);
+    std::fprintf(fp, "property float x\nproperty float y\nproperty float z\nproperty float nx\nproperty float ny\nproperty float nz\n");
+    if (v->d_colour) std::fprintf(fp, "property uchar red\nproperty uchar green\nproperty uchar blue\n");
+    std::fprintf(fp, "element face %lld\nproperty list uchar int vertex_index\nend_header\n", (long long)n);
+    size_t ok = std::fwrite(rec.data(), rec_bytes, nv, fp);
+    std::vector<unsigned char> fr((size_t)(n > 0 ? n : 1) * 13);
+    for (int64_t f = 0; f < n; ++f) { fr[13 * f] = 3; std::memcpy(fr.data() + 13 * f + 1, faces.data() + 3 * f, 12); }
+    ok += std::fwrite(fr.data(), 13, (size_t)n, fp);
+    const int bad = std::fclose(fp);
+    if (ok != nv + (size_t)n || bad) return fail(TSDF_ERR_IO, "tsdf_save_mesh_welded_ply: short write to %s", path);
+    return TSDF_OK;
 }
 
 int tsdf_save_ply(tsdf_volume *v, const char *path, float weight_thresh)

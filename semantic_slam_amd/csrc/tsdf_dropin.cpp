@@ -201,6 +201,7 @@ void TSDFfusion::SavePointCloud(const std::string &file_name)
 void TSDFfusion::SaveMesh(const std::string &file_name)
 {
 	std::cout << "Saving to " << file_name << " ... " << std::endl;  // ref: src/TSDFfusion.py.in:51
-	if (tsdf_save_mesh_ply(vol_, file_name.c_str(), 0.9f) != TSDF_OK)
+	// verts, faces, norms, colors as the Python glue's get_mesh + meshwrite hand them to the file
+	if (tsdf_save_mesh_welded_ply(vol_, file_name.c_str(), 0.9f) != TSDF_OK)
 		throw std::runtime_error(std::string("TSDFfusion::SaveMesh: ") + tsdf_last_error());
 }

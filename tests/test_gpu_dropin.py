@@ -119,19 +119,32 @@ def test_tsdffusion_native_backend(cuda, oracle, tmp_path, surface):
     oracle.save_ply(str(tmp_path / "want.ply"), t, w, dims, vs, origin)
     assert out.read_bytes() == (tmp_path / "want.ply").read_bytes()
     tri = oracle.mesh_triangles(t, w, dims[:2], 0, dims[2], vs, origin)
+    # SaveMesh writes what the Python glue's get_mesh + meshwrite do (ref: src/TSDFfusion.py.in:48-53): welded vertices with
+    # a normal and a colour each, faces as indices
     raw = mesh.read_bytes()
-    head = raw[:raw.index(b"end_header\n")]
-    assert b"property uchar red" in head and b"property uchar blue" in head     # the coloured mesh of ref: TSDFfusion.py.in:48-53
+    head = raw[:raw.index(b"end_header\n")].decode()
+    assert "property float nx" in head and "property uchar red" in head and "vertex_index" in head
+    nv = int(head.split("element vertex ")[1].split()[0])
+    nf = int(head.split("element face ")[1].split()[0])
     body = raw[raw.index(b"end_header\n") + len(b"end_header\n"):]
-    n_v = 3 * len(tri)
-    rec = np.frombuffer(body[:15 * n_v], np.uint8).reshape(n_v, 15)
-    assert len(tri) > 1000 and rec[:, :12].tobytes() == tri.tobytes()
+    assert nf == len(tri) > 1000 and len(body) == nv * 27 + nf * 13
+    rec = np.frombuffer(body[:27 * nv], np.uint8).reshape(nv, 27)
+    verts = rec[:, :12].copy().view(np.float32).reshape(nv, 3)
+    norms = rec[:, 12:24].copy().view(np.float32).reshape(nv, 3)
+    faces = np.frombuffer(body[27 * nv:], np.uint8).reshape(nf, 13)
+    assert np.all(faces[:, 0] == 3)
+    idx = faces[:, 1:].copy().view(np.int32).reshape(nf, 3)
+    assert np.array_equal(verts[idx].view(np.uint32), tri.view(np.uint32))      # the oracle's triangles, vertex for vertex
+    assert nv == len(np.unique(tri.reshape(-1, 3).view(np.uint32), axis=0)) < 3 * nf     # every distinct vertex once
+    assert np.allclose(np.linalg.norm(norms, axis=1), 1.0, atol=1e-5)
+    fn = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]).astype(np.float64)
+    assert np.mean(np.einsum("ij,ij->i", fn, norms[idx[:, 0]].astype(np.float64)) > 0) > 0.99   # normals follow the winding
     # vertex colour = the nearest voxel's fused colour
-    v = tri.reshape(-1, 3).astype(np.float64)
-    idx = np.clip(np.rint((v - origin) / vs).astype(np.int64), 0, np.array(dims) - 1)
-    q = col[(idx[:, 2] * dims[1] + idx[:, 1]) * dims[0] + idx[:, 0]]
+    v = verts.astype(np.float64)
+    vi = np.clip(np.rint((v - origin) / vs).astype(np.int64), 0, np.array(dims) - 1)
+    q = col[(vi[:, 2] * dims[1] + vi[:, 1]) * dims[0] + vi[:, 0]]
     want_rgb = np.stack([q & 255, (q >> 8) & 255, (q >> 16) & 255], axis=-1).astype(np.uint8)
-    same = np.all(rec[:, 12:] == want_rgb, axis=1)
+    same = np.all(rec[:, 24:] == want_rgb, axis=1)
     assert same.mean() > 0.999, "vertex colours must be the nearest voxel's (ties at .5 may round either way)"
     assert len(np.unique(want_rgb, axis=0)) > 50
 

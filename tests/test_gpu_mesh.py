@@ -56,6 +56,7 @@ def test_mesh_of_a_sphere_is_a_closed_manifold(cuda, oracle, tmp_path):
         vol.upload(t, w)
         tri = vol.extract_mesh()
         vol.save_mesh_ply(str(tmp_path / "sphere.ply"))
+        vol.save_mesh_welded_ply(str(tmp_path / "sphere_welded.ply"))
     assert np.array_equal(tri.view(np.uint32), oracle.mesh_triangles(t, w, (D, D), 0, D, vs, origin).view(np.uint32))
     ids, edges, directed = {}, Counter(), Counter()
     for T in tri:
@@ -72,3 +73,15 @@ def test_mesh_of_a_sphere_is_a_closed_manifold(cuda, oracle, tmp_path):
             f"property float z\nelement face {len(tri)}\nproperty list uchar int vertex_indices\nend_header\n").encode()
     assert raw.startswith(head) and len(raw) == len(head) + len(tri) * (36 + 13)
     assert raw[len(head):len(head) + 36 * len(tri)] == tri.tobytes()
+    # the welded file: V - E + F = 2 with the file's own vertex count, outward unit normals
+    rawm = (tmp_path / "sphere_welded.ply").read_bytes()
+    headm = rawm[:rawm.index(b"end_header\n")].decode()
+    nv = int(headm.split("element vertex ")[1].split()[0])
+    assert nv == len(ids) and int(headm.split("element face ")[1].split()[0]) == len(tri) and "red" not in headm
+    bodym = rawm[rawm.index(b"end_header\n") + len(b"end_header\n"):]
+    assert len(bodym) == nv * 24 + len(tri) * 13 and nv - len(edges) + len(tri) == 2
+    recm = np.frombuffer(bodym[:24 * nv], np.float32).reshape(nv, 6)
+    assert np.allclose(np.linalg.norm(recm[:, 3:], axis=1), 1.0, atol=1e-5)
+    assert np.all(np.einsum("ij,ij->i", recm[:, 3:], recm[:, :3] - c) > 0.9 * np.linalg.norm(recm[:, :3] - c, axis=1))
+    fidx = np.frombuffer(bodym[24 * nv:], np.uint8).reshape(len(tri), 13)[:, 1:].copy().view(np.int32).reshape(-1, 3)
+    assert np.array_equal(recm[:, :3][fidx].view(np.uint32), tri.view(np.uint32))
