@@ -758,7 +758,7 @@ __global__ __launch_bounds__(256, R == 2 ? 6 : 1) void integrate_multi(MultiPara
 #define TSDF_BRICK_WAVES 8   /* waves per SIMD asked of the brick instantiation (A/B builds override it) */
 #endif
 template <int R, bool NT, bool FLAT, bool LABELS = false, bool MASKS = true, bool SHORT = false, bool BRICK = false>
-__global__ __launch_bounds__(256, R == 2 ? 6 : ((BRICK && !LABELS) ? TSDF_BRICK_WAVES : 1)) void integrate_multi_inline(MultiParamsInline mp)
+__global__ __launch_bounds__(256, R == 2 ? 6 : (BRICK ? (LABELS ? 6 : TSDF_BRICK_WAVES) : 1)) void integrate_multi_inline(MultiParamsInline mp)
 {
     static_assert(!BRICK || SHORT, "the brick mapping exists for the classification's sake");
     // the single by-value parameter starts the kernarg segment (offset 0)
