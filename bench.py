@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--no-traffic", action="store_true",
                     help="do not measure roofline.traffic (two short rocprofv3 --pmc child runs of this script)")
     ap.add_argument("--no-extract", action="store_true", help="N > 1: skip the halo exchange + extraction after the timed region")
+    ap.add_argument("--voxel-mm", type=float, default=0.0, help="voxel size in mm (default: 5 at 512, 2 at 1024, else 2560 / grid)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
     a = ap.parse_args()
@@ -131,6 +132,8 @@ def grid_for(args, world):
     """Global dims and voxel size; weak scaling grows the grid with N inside the same physical box."""
     D = args.grid
     vs = {512: 0.005, 1024: 0.002}.get(D, 2.56 / D)
+    if args.voxel_mm > 0:
+        vs = args.voxel_mm / 1000.0
     dims = [D, D, D]
     part_world = args.emulate_world if (args.emulate_world > 1 and world == 1) else world
     if args.scaling == "weak" and part_world > 1:

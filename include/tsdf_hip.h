@@ -330,6 +330,16 @@ int tsdf_selftest_round(int32_t device, uint64_t *mismatches, float first_bad[4]
 int tsdf_set_kernel_variant(tsdf_volume *vol, int32_t variant);
 
 /*
+ * Tuning knob (no reference counterpart; results never depend on it): the box of voxels one wavefront owns, and
+ * classifies as a whole, in the classified launches (bricks): `quads` x 4 voxels of `rows` rows of `slices`
+ * slices.  Needs quads * rows * slices <= 64 and quads dividing dim_x / 4; (0, 0, 0) returns to the library's choice
+ * for the grid.  tsdf_brick_shape reads the shape in use ({0, 0, 0}: the grid has no brick view, dim_x % 4 != 0).
+ * The environment variable TSDF_BRICK3D="q,r,s" overrides the library's choice at tsdf_create (A/B runs).
+ */
+int tsdf_set_brick_shape(tsdf_volume *vol, int32_t quads, int32_t rows, int32_t slices);
+int tsdf_brick_shape(const tsdf_volume *vol, int32_t shape_out[3]);
+
+/*
  * Integrate AND label fusion of a known sequence of frames in the same passes over the volume: identical to
  * calling tsdf_integrate_device and tsdf_integrate_labels_device for every frame in order, but the label
  * evidence reuses the projection and depth tests Integrate has just made (the separate sweep recomputes

@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "tsdf_sync", "tsdf_download", "tsdf_copy_slices", "tsdf_upload", "tsdf_refresh_summary", "tsdf_device_ptrs", "tsdf_slab_voxels", "tsdf_frames_per_launch", "tsdf_shortcut_stats", "tsdf_classification_info",
     "tsdf_get_config", "tsdf_last_cam2base", "tsdf_set_stream", "tsdf_get_stream",
     "tsdf_count_surface", "tsdf_extract_surface", "tsdf_extract_crossings", "tsdf_extract_mesh", "tsdf_save_mesh_ply", "tsdf_save_mesh_welded_ply", "tsdf_save_ply", "tsdf_save_bin", "tsdf_load_bin", "tsdf_save_state", "tsdf_load_state",
-    "tsdf_integrate_sequence_timed", "tsdf_integrate_frames_timed", "tsdf_probe_graph_replay", "tsdf_probe_stream", "tsdf_selftest_fastdiv", "tsdf_selftest_fastdiv_band", "tsdf_selftest_round", "tsdf_set_kernel_variant", "tsdf_last_error",
+    "tsdf_integrate_sequence_timed", "tsdf_integrate_frames_timed", "tsdf_probe_graph_replay", "tsdf_probe_stream", "tsdf_selftest_fastdiv", "tsdf_selftest_fastdiv_band", "tsdf_selftest_round", "tsdf_set_kernel_variant", "tsdf_set_brick_shape", "tsdf_brick_shape", "tsdf_last_error",
     "tsdf_version", "tsdf_multiply_matrix", "tsdf_invert_matrix",
     "tsdf_labels_enable", "tsdf_compose_labels", "tsdf_integrate_labels_device", "tsdf_integrate_frames_labels_device",
     "tsdf_download_labels",
@@ -112,6 +112,8 @@ def load():
     L.tsdf_selftest_fastdiv_band.argtypes = [C.c_int32, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), f32p]
     L.tsdf_selftest_round.argtypes = [C.c_int32, C.POINTER(C.c_uint64), f32p]
     L.tsdf_set_kernel_variant.argtypes = [vp, C.c_int32]
+    L.tsdf_set_brick_shape.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
+    L.tsdf_brick_shape.argtypes = [vp, C.POINTER(C.c_int32)]
     L.tsdf_last_error.restype = C.c_char_p
     L.tsdf_version.restype = C.c_char_p
     L.tsdf_multiply_matrix.argtypes = [vp, vp, vp]
@@ -427,6 +429,15 @@ class Volume:
 
     def set_kernel_variant(self, v):
         check(self.lib.tsdf_set_kernel_variant(self._h, v), "tsdf_set_kernel_variant")
+
+    def set_brick_shape(self, quads=0, rows=0, slices=0):
+        """The box a wavefront owns in classified launches (tuning only; (0, 0, 0) = the library's choice)."""
+        check(self.lib.tsdf_set_brick_shape(self._h, quads, rows, slices), "tsdf_set_brick_shape")
+
+    def brick_shape(self):
+        out = (C.c_int32 * 3)()
+        check(self.lib.tsdf_brick_shape(self._h, out), "tsdf_brick_shape")
+        return tuple(out)
 
     # -- per-voxel label fusion ----------------------------------------------------------------
     def labels_enable(self, prob_threshold=0.5):

@@ -111,6 +111,7 @@ struct tsdf_volume {
     int nseg;              // chunks per row when dim_x % 256 == 0 (row-mapped kernels), else 0
     int chunks_per_slice;  // ceil(dim_x*dim_y / 256)
     bool flat;             // dim_x % 256 != 0: summary-maintaining launches use the flat mapping
+    int brick_q, brick_r, brick_s;   // wavefront brick of the classified launches (choose_brick / tsdf_set_brick_shape); q = 0: none
     bool flags_known_zero;
     // depth tile summaries of the frames of one fused launch (allocated on first use), optional counters
     float2 *d_tiles;
@@ -148,6 +149,9 @@ struct tsdf_batch {
     int slot_next;
     int2 *d_slice_map;
     int total_slices, max_blocks;
+    int2 *d_group_map;           // {object, slice group}: the brick launches' z index (a brick spans brick_s slices)
+    int total_groups;
+    std::vector<int> group_s;    // the brick_s of every member the group map was built with
     // per-object depth tile tables of the current frame and the class of every workgroup of the launch
     float2 *d_tiles;
     size_t tiles_per_object;
@@ -167,6 +171,47 @@ int bind_device(tsdf_volume *v, bool flush = true)
     HIP_TRY(hipSetDevice(v->cfg.device));
     if (flush && v->pend_count > 0 && !v->in_flush) return flush_pending(v);
     return TSDF_OK;
+}
+
+// The wavefront brick of classified launches: q quads (4q voxels) of r rows of s slices, q * r * s <= 64 lanes, q a
+// divisor of the row's quads.  A brick is classified as a whole, so what counts is how tightly its box projects
+// (few depth tiles, a short range of camera depths) and how it coalesces (16q-byte row pieces).
+bool brick_shape_ok(const tsdf_config &c, int q, int r, int s)
+{
+    return c.dim_x % 4 == 0 && q >= 1 && r >= 1 && s >= 1 && q * r * s <= 64 && (c.dim_x / 4) % q == 0;
+}
+
+void choose_brick(tsdf_volume *v)
+{
+    const tsdf_config &c = v->cfg;
+    v->brick_q = 0; v->brick_r = 0; v->brick_s = 1;
+    if (c.dim_x % 4 != 0) return;
+    const int quads = c.dim_x / 4;
+    if (const char *e = std::getenv("TSDF_BRICK3D")) {      // A/B knob: "q,r,s"
+        int q = 0, r = 0, sl = 0;
+        if (std::sscanf(e, "%d,%d,%d", &q, &r, &sl) == 3 && brick_shape_ok(c, q, r, sl)) {
+            v->brick_q = q; v->brick_r = r; v->brick_s = sl;
+            return;
+        }
+    }
+    // The library's choice: the shape that lets the fewest bricks touch a surface band.  A brick of X x Y x Z voxels is
+    // claimed unless the band (about 10 voxels thick) crosses its box grown by the slack of the depth tiles it is tested
+    // against (about 8 voxels either way in x and y at the usual 1 - 2 pixels per voxel), so the share of per-voxel
+    // bricks goes like (X + 8)(Y + 8)(Z + 10) / XYZ; idle lanes and row pieces under 64 bytes (q < 4) cost on top.
+    // Measured over shapes at 512^3 S-surf (ms per frame, fused): 2,4,8 0.0431; 2,8,4 0.0475; 4,4,4 0.0479; 4,8,2
+    // 0.0492; 1,8,8 0.0515; 8,8,1 0.0528; 16,4,1 0.0669 -- the same order as this cost; 200^3 @ 4 mm and the 1024^3
+    // trajectory agree.
+    const int nz = c.z_end - c.z_begin;
+    double best = 1e300;
+    for (int q = 1; q <= 64 && q <= quads; ++q) {
+        if (quads % q) continue;
+        for (int sl = 1; q * sl <= 64 && sl <= std::max(nz, 1); ++sl) {
+            const int r = std::min(64 / (q * sl), std::max(c.dim_y, 1));
+            const double X = 4.0 * q, Y = r, Z = sl;
+            const double cost = (X + 8.0) * (Y + 8.0) * (Z + 10.0) / (X * Y * Z) * (1.0 + 0.25 / q) * 64.0 / (q * r * sl);
+            if (cost < best) { best = cost; v->brick_q = q; v->brick_r = r; v->brick_s = sl; }
+        }
+    }
 }
 
 tsdfk::IntegrateParams make_params(const tsdf_volume *v, const float *depth_dev,
@@ -194,19 +239,12 @@ tsdfk::IntegrateParams make_params(const tsdf_volume *v, const float *depth_dev,
     p.quads_per_row = c.dim_x / 4;
     p.quads_per_slice = (int)((int64_t)c.dim_x * c.dim_y / 4);
     p.chunks_per_slice = v->chunks_per_slice;
-    // brick view (tsdf_multiframe.hip.h, BRICK): the widest brick row of at most 16 quads that divides a row, as many
-    // rows as fit 64 lanes; none when a row only divides into pieces narrower than 8 quads (poorly coalesced)
-    p.brick_q = 0; p.brick_r = 0; p.bricks_per_group = 0; p.brick_groups = 0;
-    if (c.dim_x % 4 == 0) {
-        for (int q = 16; q >= 8; --q) {
-            if (p.quads_per_row % q == 0) {
-                p.brick_q = q;
-                p.brick_r = 64 / q;
-                p.bricks_per_group = p.quads_per_row / q;
-                p.brick_groups = (c.dim_y + p.brick_r - 1) / p.brick_r;
-                break;
-            }
-        }
+    // brick view (tsdf_multiframe.hip.h, BRICK): the volume's wavefront brick, chosen at creation (choose_brick)
+    p.brick_q = v->brick_q; p.brick_r = v->brick_r; p.brick_s = v->brick_s > 0 ? v->brick_s : 1;
+    p.bricks_per_group = 0; p.brick_groups = 0;
+    if (p.brick_q > 0) {
+        p.bricks_per_group = p.quads_per_row / p.brick_q;
+        p.brick_groups = (c.dim_y + p.brick_r - 1) / p.brick_r;
     }
     // The shared-reciprocal projection (tsdf_kernels.hip.h, fast_div2) is exact when no operand
     // needs div_scale's pre-scaling: bound every camera-frame coordinate of the slab by
@@ -359,7 +397,7 @@ int classify_single(tsdf_volume *v, tsdfk::IntegrateParams &p, int nbx, int nby,
 // The same with wavefront bricks (rows that divide into them): class per brick, then the brick kernel.  Queues the launch.
 int launch_masked_bricks(tsdf_volume *v, tsdfk::IntegrateParams &p)
 {
-    const int blocks = (p.brick_groups * p.bricks_per_group + 3) / 4, nz = p.nz;
+    const int blocks = (p.brick_groups * p.bricks_per_group + 3) / 4, nz = (p.nz + p.brick_s - 1) / p.brick_s;   // slice groups
     const size_t per = tile_table_elems_host(p.tiles_w, p.tiles_h);
     if (!v->d_tiles) HIP_TRY(hipMalloc((void **)&v->d_tiles, tsdfk::kMaxFramesPerLaunch * per * sizeof(float2)));
     const size_t n_bricks = (size_t)blocks * nz * 4;
@@ -601,7 +639,7 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
         // workgroups then share their (x, y) footprint, i.e. the windows of the launch's up to 32 depth frames (39 MB,
         // more than the L2s hold) they gather from.  Measured at 512^3 S-surf with a depth frame per pose: 0.1325 ->
         // 0.1148 ms per frame; 1024^3 on the fr3 trajectory 0.529 -> 0.376; no change with one resident frame.
-        mi.z_fastest = v->variant != 9 ? 1 : 0;
+        mi.z_fastest = v->variant == 9 ? 0 : (v->variant == 10 ? 1 : 2);   // variant 10: slices fastest, not rotated (A/B)
         {
             bool any_mask = false;
             for (int f = 0; f < n && masks_dev; ++f) any_mask = any_mask || masks_dev[f] != nullptr;
@@ -662,10 +700,11 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
             // rows / 1024 consecutive voxels, classified per workgroup -- for A/B and tests)
             const bool bricks = classify && v->variant != 11 && mi.common.brick_q > 0;
             dim3 grid_bricks(1, 1, 1);
+            const int nz_groups = (nz + mi.common.brick_s - 1) / mi.common.brick_s;   // a brick spans brick_s slices
             if (bricks) {
                 const unsigned wgs = (unsigned)(((int64_t)mi.common.brick_groups * mi.common.bricks_per_group + 3) / 4);
                 if (wgs > 65535u) mi.z_fastest = 0;   // the slow grid dimensions hold 65535 at most
-                grid_bricks = mi.z_fastest ? dim3((unsigned)nz, 1, wgs) : dim3(wgs, 1, (unsigned)nz);
+                grid_bricks = mi.z_fastest ? dim3((unsigned)nz_groups, 1, wgs) : dim3(wgs, 1, (unsigned)nz_groups);
             }
             if (bricks && label_ims)
                 hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, true, false, true, true>), grid_bricks, block, 0, v->stream, mi);
@@ -1048,6 +1087,7 @@ int tsdf_create(const tsdf_config *cfg, tsdf_volume **out)
     v->flat = cfg->dim_x % 256 != 0;
     v->nseg = v->flat ? 0 : cfg->dim_x / 256;
     v->chunks_per_slice = (int)(((int64_t)cfg->dim_x * cfg->dim_y + 255) / 256);
+    choose_brick(v);
     v->n_flags = cfg->dim_x % 4 == 0 ? (size_t)v->chunks_per_slice * (size_t)(cfg->z_end - cfg->z_begin) : 0;
     if ((e = hipMalloc((void **)&v->d_flags, (v->n_flags ? v->n_flags : 1) * sizeof(uint32_t))) != hipSuccess)
         return cleanup(fail(TSDF_ERR_HIP, "tsdf_create: hipMalloc of the summary: %s", hipGetErrorString(e)));
@@ -1458,6 +1498,24 @@ int tsdf_set_kernel_variant(tsdf_volume *v, int32_t variant)
     return TSDF_OK;
 }
 
+int tsdf_set_brick_shape(tsdf_volume *v, int32_t quads, int32_t rows, int32_t slices)
+{
+    if (!v) return fail(TSDF_ERR_INVALID, "tsdf_set_brick_shape: NULL handle");
+    if (quads == 0 && rows == 0 && slices == 0) { choose_brick(v); return TSDF_OK; }
+    if (!brick_shape_ok(v->cfg, quads, rows, slices))
+        return fail(TSDF_ERR_INVALID, "tsdf_set_brick_shape: %d quads x %d rows x %d slices: needs quads * rows * slices <= 64 and "
+                    "quads dividing dim_x / 4 = %d", quads, rows, slices, v->cfg.dim_x / 4);
+    v->brick_q = quads; v->brick_r = rows; v->brick_s = slices;
+    return TSDF_OK;
+}
+
+int tsdf_brick_shape(const tsdf_volume *v, int32_t shape_out[3])
+{
+    if (!v || !shape_out) return fail(TSDF_ERR_INVALID, "tsdf_brick_shape: NULL argument");
+    shape_out[0] = v->brick_q; shape_out[1] = v->brick_q ? v->brick_r : 0; shape_out[2] = v->brick_q ? v->brick_s : 0;
+    return TSDF_OK;
+}
+
 int tsdf_selftest_fastdiv(int32_t device, uint64_t seed, uint64_t n_samples, float fx, float cx,
                           uint64_t *mismatches, float first_bad[4])
 {
@@ -1853,6 +1911,7 @@ int tsdf_batch_destroy(tsdf_batch *b)
         if (b->slot_done[i]) (void)hipEventDestroy(b->slot_done[i]);
     }
     if (b->d_slice_map) (void)hipFree(b->d_slice_map);
+    if (b->d_group_map) (void)hipFree(b->d_group_map);
     if (b->d_tiles) (void)hipFree(b->d_tiles);
     if (b->d_wg_class) (void)hipFree(b->d_wg_class);
     if (b->d_brick_class) (void)hipFree(b->d_brick_class);
@@ -1875,7 +1934,7 @@ int tsdf_batch_create(const tsdf_config *cfgs, int32_t n, tsdf_batch **out)
     tsdf_batch *b = new (std::nothrow) tsdf_batch();
     if (!b) return fail(TSDF_ERR_INVALID, "tsdf_batch_create: out of host memory");
     b->device = cfgs[0].device;
-    b->stream = nullptr; b->d_slice_map = nullptr; b->slot_next = 0;
+    b->stream = nullptr; b->d_slice_map = nullptr; b->d_group_map = nullptr; b->total_groups = 0; b->slot_next = 0;
     b->d_tiles = nullptr; b->tiles_per_object = 0; b->d_wg_class = nullptr; b->d_brick_class = nullptr; b->brick_class_bytes = 0;
     b->total_slices = b->max_blocks = 0;
     for (int i = 0; i < kStageSlots; ++i) {
@@ -1990,7 +2049,25 @@ int tsdf_batch_integrate_device(tsdf_batch *b, const float *depth_dev, const uin
         brick_blocks = std::max(brick_blocks, (q.brick_groups * q.bricks_per_group + 3) / 4);
     }
     if (bricks) {
-        const size_t n_bricks = (size_t)brick_blocks * b->total_slices * 4;
+        // z index of the brick launches: slice groups (rebuilt when a member's brick depth changed: tsdf_set_brick_shape)
+        bool same = b->d_group_map != nullptr && (int)b->group_s.size() == n;
+        for (int i = 0; i < n && same; ++i) same = b->group_s[i] == b->h_params[s][i].brick_s;
+        if (!same) {
+            std::vector<int2> gmap;
+            b->group_s.assign((size_t)n, 1);
+            for (int i = 0; i < n; ++i) {
+                const tsdfk::IntegrateParams &q = b->h_params[s][i];
+                b->group_s[i] = q.brick_s;
+                for (int g = 0; g < (q.nz + q.brick_s - 1) / q.brick_s; ++g) gmap.push_back(make_int2(i, g));
+            }
+            HIP_TRY(hipStreamSynchronize(b->stream));
+            if (b->d_group_map) HIP_TRY(hipFree(b->d_group_map));
+            b->d_group_map = nullptr;
+            HIP_TRY(hipMalloc((void **)&b->d_group_map, std::max<size_t>(gmap.size(), 1) * sizeof(int2)));
+            HIP_TRY(hipMemcpy(b->d_group_map, gmap.data(), gmap.size() * sizeof(int2), hipMemcpyHostToDevice));
+            b->total_groups = (int)gmap.size();
+        }
+        const size_t n_bricks = (size_t)brick_blocks * b->total_groups * 4;
         if (b->brick_class_bytes < n_bricks) {
             if (b->d_brick_class) HIP_TRY(hipFree(b->d_brick_class));
             b->d_brick_class = nullptr;
@@ -1999,9 +2076,9 @@ int tsdf_batch_integrate_device(tsdf_batch *b, const float *depth_dev, const uin
             b->brick_class_bytes = n_bricks;
         }
         hipLaunchKernelGGL(tsdfk::classify_bricks_batched, dim3((unsigned)((n_bricks + 255) / 256)), dim3(256), 0, b->stream,
-                           b->d_params[s], b->d_poses[s], b->d_slice_map, b->d_brick_class, brick_blocks, b->total_slices);
-        hipLaunchKernelGGL((tsdfk::integrate_multi_batched_bricks<true>), dim3(brick_blocks, 1, b->total_slices), block, 0, b->stream,
-                           b->d_params[s], b->d_poses[s], b->d_slice_map, b->d_brick_class);
+                           b->d_params[s], b->d_poses[s], b->d_group_map, b->d_brick_class, brick_blocks, b->total_groups);
+        hipLaunchKernelGGL((tsdfk::integrate_multi_batched_bricks<true>), dim3(brick_blocks, 1, b->total_groups), block, 0, b->stream,
+                           b->d_params[s], b->d_poses[s], b->d_group_map, b->d_brick_class);
     } else if (classify) {
         const size_t n_wg = (size_t)b->max_blocks * b->total_slices;
         hipLaunchKernelGGL(tsdfk::classify_workgroups_batched, dim3((unsigned)((n_wg + 255) / 256)), dim3(256), 0, b->stream,

@@ -52,12 +52,13 @@ struct IntegrateParams {
     // flags[z * chunks_per_slice + c].  For dim_x % 256 == 0 a chunk IS a row segment, so both
     // mappings address the same words.
     int quads_per_row, quads_per_slice, chunks_per_slice;
-    // Brick view of a slice (tsdf_multiframe.hip.h, BRICK): a wavefront owns brick_q quads (4 * brick_q voxels) of
-    // brick_r consecutive rows, brick_q * brick_r <= 64 lanes; a row group holds bricks_per_group = quads_per_row /
-    // brick_q bricks, a slice brick_groups = ceil(dim_y / brick_r) groups; bricks are numbered group by group and a
-    // workgroup takes four consecutive ones.  512-voxel rows: 16 x 4 (64 x 4 voxels); the reference's 200-voxel rows:
-    // 10 x 6 (40 x 6 voxels).  brick_q = 0: no brick view (rows too ragged for one).
-    int brick_q, brick_r, bricks_per_group, brick_groups;
+    // Brick view of the slab (tsdf_multiframe.hip.h, BRICK): a wavefront owns brick_q quads (4 * brick_q voxels) of
+    // brick_r consecutive rows of brick_s consecutive slices, brick_q * brick_r * brick_s <= 64 lanes (lane = (slice *
+    // brick_r + row) * brick_q + quad); a row group holds bricks_per_group = quads_per_row / brick_q bricks, a slice
+    // group brick_groups = ceil(dim_y / brick_r) row groups; bricks are numbered group by group, a workgroup takes four
+    // consecutive ones, and the launch's z index counts slice groups.  brick_q = 0: no brick view (dim_x % 4 != 0).
+    // The shape is the host's choice per volume (tsdf_capi.hip, choose_brick; tsdf_set_brick_shape).
+    int brick_q, brick_r, brick_s, bricks_per_group, brick_groups;
     // host-proved magnitude bounds that make the shared-reciprocal projection exact (see fast_div2)
     int fast_ok;
     // 2^-20 <= trunc <= 2^20 and max_depth <= 2^59: diff / trunc may go through the shared refined reciprocal

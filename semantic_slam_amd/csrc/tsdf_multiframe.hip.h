@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void tile_sparse_table(float2 *tables, int tw,
 // per-voxel values, and rounding is monotone: d - cz >= trunc in the reals implies RN(d - cz) >= trunc.  A NaN or an
 // infinity in the corner arithmetic fails a comparison and yields 0.
 __device__ __forceinline__ int classify_patch(const IntegrateParams &p, const FramePose *__restrict__ qp, const int xa,
-                                              const int xb, const int ya, const int yb, const int gz)
+                                              const int xb, const int ya, const int yb, const int gz, const int gz1 = -1)
 {
     const FramePose q = *qp;      // this lane's frame
     if (q.tiles == nullptr) return 0;
@@ -196,6 +196,25 @@ __device__ __forceinline__ int classify_patch(const IntegrateParams &p, const Fr
     };
     corner(dxa, dya); corner(dxb, dya);
     corner(dxa, dyb); corner(dxb, dyb);   // the same two again when ya == yb
+    if (gz1 > gz) {
+        // a box of slices gz .. gz1: camera-frame coordinates are affine in z too, so the far slice's corners complete
+        // the convex hull (and the z extremes)
+        const float dz1 = (p.oz + (float)gz1 * p.vs) - q.tz;
+        const float zx1 = q.rx2 * dz1, zy1 = q.ry2 * dz1, zz1 = q.rz2 * dz1;
+        auto corner1 = [&](const float dx, const float dy) {
+            const float cx = q.rx0 * dx + q.rx1 * dy + zx1;
+            const float cy = q.ry0 * dx + q.ry1 * dy + zy1;
+            const float cz = q.rz0 * dx + q.rz1 * dy + zz1;
+            const float inv = __builtin_amdgcn_rcpf(cz);
+            const float u = p.fx * (cx * inv) + p.cx, v = p.fy * (cy * inv) + p.cy;
+            umin = fminf(umin, u); umax = fmaxf(umax, u);
+            vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
+            czmin = fminf(czmin, cz); czmax = fmaxf(czmax, cz);
+            finite &= (u == u) & (v == v) & (cz == cz);
+        };
+        corner1(dxa, dya); corner1(dxb, dya);
+        corner1(dxa, dyb); corner1(dxb, dyb);
+    }
     if (!(finite & (czmin > q.cz_short) & (czmax < 3.0e38f))) return 0;
     // pixel box that contains the rounded pixel of every voxel of the patch
     const float u0 = umin - p.px_margin_u, u1 = umax + p.px_margin_u;
@@ -272,40 +291,45 @@ __global__ __launch_bounds__(256) void classify_workgroups_batched(const Integra
 }
 
 // One masked frame into one volume, with bricks: the class of every wavefront brick, one thread per brick; index =
-// (slice * blocks + workgroup) * 4 + wavefront, blocks = workgroups per slice.
-__global__ __launch_bounds__(256) void classify_bricks(IntegrateParams p, FramePose pose, uint8_t *cls, int blocks, int nz)
+// (slice group * blocks + workgroup) * 4 + wavefront, blocks = workgroups per slice group (brick_s slices each).
+__global__ __launch_bounds__(256) void classify_bricks(IntegrateParams p, FramePose pose, uint8_t *cls, int blocks, int nzg)
 {
     const int id = blockIdx.x * 256 + threadIdx.x;
-    if (id >= blocks * nz * 4) return;
+    if (id >= blocks * nzg * 4) return;
     const int wave = id & 3, wg = (id >> 2) % blocks, lz = (id >> 2) / blocks;
     const int brick = wg * 4 + wave;
     const int g = brick / p.bricks_per_group, i = brick - g * p.bricks_per_group;
     int c = 2;
     if (g < p.brick_groups) {
         const int xa = i * p.brick_q * 4, ya = g * p.brick_r;
-        c = classify_patch(p, &pose, xa, xa + p.brick_q * 4 - 1, ya, min(ya + p.brick_r - 1, p.dim_y - 1), p.z_begin + lz);
+        const int z0 = lz * p.brick_s, z1 = min(z0 + p.brick_s - 1, p.nz - 1);
+        c = classify_patch(p, &pose, xa, xa + p.brick_q * 4 - 1, ya, min(ya + p.brick_r - 1, p.dim_y - 1), p.z_begin + z0,
+                           p.z_begin + z1);
     }
     cls[id] = (uint8_t)c;
 }
 
-// The batched form with bricks: one thread per wavefront brick of the launch; index = (slice of the launch *
-// max_blocks + workgroup) * 4 + wavefront.  Each object brings its own brick view (IntegrateParams::brick_*).
+// The batched form with bricks: one thread per wavefront brick of the launch; index = (slice group of the launch *
+// max_blocks + workgroup) * 4 + wavefront.  Each object brings its own brick view (IntegrateParams::brick_*);
+// group_map[z] = {object, slice group within it}.
 __global__ __launch_bounds__(256) void classify_bricks_batched(const IntegrateParams *__restrict__ params,
                                                                const FramePose *__restrict__ poses,
-                                                               const int2 *__restrict__ slice_map, uint8_t *cls,
-                                                               int max_blocks, int total_slices)
+                                                               const int2 *__restrict__ group_map, uint8_t *cls,
+                                                               int max_blocks, int total_groups)
 {
     const int id = blockIdx.x * 256 + threadIdx.x;
-    if (id >= max_blocks * total_slices * 4) return;
+    if (id >= max_blocks * total_groups * 4) return;
     const int wave = id & 3, wg = (id >> 2) % max_blocks, z = (id >> 2) / max_blocks;
-    const int2 m = slice_map[z];
+    const int2 m = group_map[z];
     const IntegrateParams p = params[m.x];
     const int brick = wg * 4 + wave;
     const int g = brick / p.bricks_per_group, i = brick - g * p.bricks_per_group;
     int c = 2;                                   // a brick past the end of this object's slice: nothing there
     if (g < p.brick_groups) {
         const int xa = i * p.brick_q * 4, ya = g * p.brick_r;
-        c = classify_patch(p, poses + m.x, xa, xa + p.brick_q * 4 - 1, ya, min(ya + p.brick_r - 1, p.dim_y - 1), p.z_begin + m.y);
+        const int z0 = m.y * p.brick_s, z1 = min(z0 + p.brick_s - 1, p.nz - 1);
+        c = classify_patch(p, poses + m.x, xa, xa + p.brick_q * 4 - 1, ya, min(ya + p.brick_r - 1, p.dim_y - 1), p.z_begin + z0,
+                           p.z_begin + z1);
     }
     cls[id] = (uint8_t)c;
 }
@@ -334,7 +358,10 @@ struct MultiParamsInline {
     LabelState labels;   // read by the LABELS kernels only
     // workgroup order: 0 = memory order (x blocks fastest, then y, then slices), 1 = slices fastest (grid launched as
     // (slices, y blocks, x blocks)): consecutively dispatched workgroups then share their (x, y) footprint and with
-    // it the windows of the launch's depth frames they gather from
+    // it the windows of the launch's depth frames they gather from; 2 = slices fastest AND rotated: the workgroup at
+    // grid position (z, y, x) takes slice group (z + x + y) mod n.  Workgroups are dealt to the 8 XCDs by their linear
+    // index, so with a slice count that is a multiple of 8 order 1 gives every slice to ONE XCD -- and a surface that
+    // lies across few slices (a wall facing the camera) then keeps one or two XCDs busy while the others idle
     int z_fastest;
 };
 
@@ -371,19 +398,23 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
     static_assert(!BRICK || (R == 1 && !FLAT), "bricks are their own mapping");
     int xg, gy0;
     size_t row0, flag0;
+    int lzz = lz;            // the lane's slice of the slab (BRICK: lz counts groups of brick_s slices)
     // the summary word of the lane's quad: row segment (dim_x % 256 == 0) or 256-voxel chunk of the slice's linear view
     auto brick_flag_index = [&](const int gy, const int quad) -> size_t {
-        if (p.nseg > 0) return ((size_t)lz * p.dim_y + gy) * (size_t)p.nseg + (size_t)(quad >> 6);
-        return (size_t)lz * p.chunks_per_slice + (size_t)((gy * p.quads_per_row + quad) >> 6);
+        if (p.nseg > 0) return ((size_t)lzz * p.dim_y + gy) * (size_t)p.nseg + (size_t)(quad >> 6);
+        return (size_t)lzz * p.chunks_per_slice + (size_t)((gy * p.quads_per_row + quad) >> 6);
     };
     if constexpr (BRICK) {
         const int brick = b0 * 4 + (int)threadIdx.y;
         const int g = brick / p.bricks_per_group, i = brick - g * p.bricks_per_group;
-        const int rr = (int)threadIdx.x / p.brick_q, qq = (int)threadIdx.x - rr * p.brick_q;
+        const int per = p.brick_q * p.brick_r;
+        const int zz = (int)threadIdx.x / per, rem = (int)threadIdx.x - zz * per;
+        const int rr = rem / p.brick_q, qq = rem - rr * p.brick_q;
         xg = i * p.brick_q + qq;
         gy0 = g * p.brick_r + rr;
-        if (g >= p.brick_groups || rr >= p.brick_r || gy0 >= p.dim_y) return;
-        row0 = ((size_t)lz * p.dim_y + gy0) * (size_t)p.dim_x + (size_t)xg * 4;
+        lzz = lz * p.brick_s + zz;
+        if (g >= p.brick_groups || zz >= p.brick_s || lzz >= p.nz || gy0 >= p.dim_y) return;
+        row0 = ((size_t)lzz * p.dim_y + gy0) * (size_t)p.dim_x + (size_t)xg * 4;
         flag0 = brick_flag_index(gy0, xg);
     } else if constexpr (FLAT) {
         const int chunk = b0 * 4 + threadIdx.y;
@@ -400,7 +431,7 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
         row0 = ((size_t)lz * p.dim_y + gy0) * (size_t)p.dim_x + (size_t)xg * 4;
         flag0 = ((size_t)lz * p.dim_y + gy0) * (size_t)p.nseg + b0;
     }
-    const int gz = p.z_begin + lz;
+    const int gz = p.z_begin + lzz;
 
     // ---- voxel state held in registers across the frames ----------------------------------------
     uint32_t fl[R];
@@ -768,7 +799,11 @@ __global__ __launch_bounds__(256, R == 2 ? 6 : (BRICK ? (LABELS ? 6 : TSDF_BRICK
     frames_ptr frames = (frames_ptr)(base + offsetof(MultiParamsInline, frames));
     unsigned int free_frames = 0u, skip_frames = 0u;
     const int wg_x = mp.z_fastest ? (int)blockIdx.z : (int)blockIdx.x, wg_y = (int)blockIdx.y;
-    const int wg_z = mp.z_fastest ? (int)blockIdx.x : (int)blockIdx.z;
+    int wg_z = mp.z_fastest ? (int)blockIdx.x : (int)blockIdx.z;
+    if (mp.z_fastest == 2) {
+        wg_z += (int)((unsigned)(wg_x + wg_y) % gridDim.x);
+        if (wg_z >= (int)gridDim.x) wg_z -= (int)gridDim.x;
+    }
     if constexpr (SHORT) {
         // Patch classification in the prologue.  The first wavefront stages the frame blocks in LDS (coalesced); then
         //   row / flat mapping: it classifies the workgroup's patch (256 x 4 voxels, or 1024 consecutive ones), one frame
@@ -821,10 +856,11 @@ __global__ __launch_bounds__(256, R == 2 ? 6 : (BRICK ? (LABELS ? 6 : TSDF_BRICK
             const int brick = wg_x * 4 + (int)threadIdx.y;
             const int g = brick / p.bricks_per_group, i = brick - g * p.bricks_per_group;
             const int xa = i * p.brick_q * 4, ya = g * p.brick_r;
+            const int z0 = wg_z * p.brick_s, z1 = min(z0 + p.brick_s - 1, p.nz - 1);
             int cls = 0;
             if (g < p.brick_groups && lane < mp.n_frames)
                 cls = classify_patch(p, s_frames + lane, xa, xa + p.brick_q * 4 - 1, ya, min(ya + p.brick_r - 1, p.dim_y - 1),
-                                     p.z_begin + wg_z);
+                                     p.z_begin + z0, p.z_begin + z1);
             const unsigned long long fb = __ballot(cls == 1), sb = __ballot(cls == 2);
             free_frames = (unsigned int)fb;
             skip_frames = (unsigned int)sb;
@@ -908,7 +944,7 @@ __global__ __launch_bounds__(256) void integrate_multi_batched(const IntegratePa
         multi_body<1, NT, true>(p, poses + m.x, 1, blockIdx.x, 0, m.y);
 }
 
-// One masked frame into one volume over bricks with a class per wavefront (classify_bricks).
+// One masked frame into one volume over bricks with a class per wavefront (classify_bricks); grid.z = slice groups.
 template <bool NT>
 __global__ __launch_bounds__(256, 8) void integrate_single_bricks(IntegrateParams p, FramePose pose)
 {
@@ -919,15 +955,16 @@ __global__ __launch_bounds__(256, 8) void integrate_single_bricks(IntegrateParam
 
 // The batched launch over bricks with a class per wavefront (classify_bricks_batched): per-object volumes are fed
 // depth x their instance mask, so most bricks of most objects see nothing -- by rows, slices AND columns.
+// grid.z = slice groups of the launch (group_map[z] = {object, slice group within it}).
 template <bool NT>
 __global__ __launch_bounds__(256, 8) void integrate_multi_batched_bricks(const IntegrateParams *__restrict__ params,
                                                                         const FramePose *__restrict__ poses,
-                                                                        const int2 *__restrict__ slice_map,
+                                                                        const int2 *__restrict__ group_map,
                                                                         const uint8_t *__restrict__ wg_class)
 {
     const unsigned c = wg_class[(blockIdx.x + gridDim.x * blockIdx.z) * 4u + threadIdx.y];   // wave-uniform
     if (c == 2u) return;
-    const int2 m = slice_map[blockIdx.z];
+    const int2 m = group_map[blockIdx.z];
     const IntegrateParams p = params[m.x];
     multi_body<1, NT, false, false, true, true, true>(p, poses + m.x, 1, blockIdx.x, 0, m.y, LabelState(), c == 1u ? 1u : 0u, 0u);
 }

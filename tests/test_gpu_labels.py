@@ -105,11 +105,14 @@ def test_config4_slab_of_2048_cube_with_labels(cuda, oracle):
     assert seen > 1000 and np.count_nonzero(lab) > 10000, (seen, int(np.count_nonzero(lab)))
 
 
+@pytest.mark.parametrize("shape", [None, (2, 8, 4), (2, 5, 6)])   # the wavefront brick: the library's choice, spanning slices
 @pytest.mark.parametrize("variant", [0, 8, 7])   # classified through wavefront bricks: per launch / always / never
 @pytest.mark.parametrize("dims,n_frames", [((256, 40, 24), 7), ((200, 40, 24), 35)])   # row mapping; flat mapping across a pass boundary
-def test_fused_integrate_and_labels_equal_separate_passes(cuda, oracle, dims, n_frames, variant):
+def test_fused_integrate_and_labels_equal_separate_passes(cuda, oracle, dims, n_frames, variant, shape):
     """tsdf_integrate_frames_labels_device == tsdf_integrate_device + tsdf_integrate_labels_device per frame == the
     oracle's two functions, bit for bit, for the TSDF, the weights and the three label arrays."""
+    if shape is not None and variant != 8:
+        pytest.skip("brick shapes: with the classification forced on")
     vs = 2.0 / dims[0]
     origin = synth.surf_volume(dims[0], vs, 0.6)
     cfg = capi.make_config(dims, vs, origin)
@@ -134,6 +137,8 @@ def test_fused_integrate_and_labels_equal_separate_passes(cuda, oracle, dims, n_
     poses = np.stack([f[0] for f in frames])
     with capi.Volume(cfg) as vol:
         vol.set_kernel_variant(variant)
+        if shape is not None:
+            vol.set_brick_shape(*shape)
         vol.labels_enable(0.5)
         vol.integrate_frames_labels_device([d.data_ptr() for d, _, _ in keep], [l.data_ptr() for _, l, _ in keep],
                                            [s_.data_ptr() for _, _, s_ in keep], poses)

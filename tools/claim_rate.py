@@ -1,28 +1,51 @@
 #!/usr/bin/env python3
-"""What the patch classification claims on S-surf 512^3 (depth re-rendered per pose), forced on: wavefront-frames that
-took the per-voxel path / were updated as free space without projecting a voxel / were skipped -- bricks per wavefront
-(variant 8) against rows per workgroup (variant 11)."""
+"""What the brick classification claims, forced on (variant 8), by brick shape: wavefront-frames that took the per-voxel
+path / were updated as free space without projecting a voxel / were skipped, and the time per frame of the fused path.
+
+    python tools/claim_rate.py [--workload ssurf|traj] [--grid 512] [--shapes 8,8,1:4,8,2:2,4,8]
+"""
+import argparse
 import os
 import sys
+import time
 
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
-from semantic_slam_amd import capi, synth  # noqa: E402
+import bench  # noqa: E402
+from semantic_slam_amd import capi  # noqa: E402
 
-D, vs = 512, 0.005
+ap = argparse.ArgumentParser()
+ap.add_argument("--workload", default="ssurf")
+ap.add_argument("--grid", type=int, default=512)
+ap.add_argument("--shapes", default="16,4,1:8,8,1:4,8,2:4,4,4:2,4,8")
+a = ap.parse_args()
+D = a.grid
+vs = {512: 0.005, 1024: 0.002}.get(D, 2.56 / D)
 dims = (D, D, D)
-origin = synth.surf_volume(D, vs, 1.0)
-scene = synth.SurfScene(dims, vs, origin)
-poses = np.stack([scene.pose(k, 64) for k in range(64)])
-dev = [torch.from_numpy(scene.depth(p, quantize=True)).cuda() for p in poses]
-for variant in (8, 11):
-    with capi.Volume(capi.make_config(dims, vs, origin)) as vol:
-        vol.set_kernel_variant(variant)
-        vol.integrate_frames_device([d.data_ptr() for d in dev], poses)      # steady state: second pass counted
+W = bench.Workload(a.workload, dims, vs)
+n = min(64, W.n_pose)
+poses = W.poses[:n]
+dev = [torch.from_numpy(np.ascontiguousarray(W.depths[i % len(W.depths)])).cuda() for i in range(n)]
+cfg = capi.make_config(dims, vs, W.origin, trunc=W.trunc, base2world=W.base2world)
+print(f"{a.workload} {D}^3 @ {vs * 1000:g} mm, {n} frames")
+for shape in a.shapes.split(":"):
+    q, r, s = (int(x) for x in shape.split(","))
+    with capi.Volume(cfg) as vol:
+        vol.set_kernel_variant(8)
+        vol.set_brick_shape(q, r, s)
+        ptrs = [d.data_ptr() for d in dev]
+        vol.integrate_frames_device(ptrs, poses)      # steady state: second pass counted
         vol.shortcut_stats(True)
-        vol.integrate_frames_device([d.data_ptr() for d in dev], poses)
+        vol.integrate_frames_device(ptrs, poses)
         pv, fr, sk = vol.shortcut_stats(False)
         tot = pv + fr + sk
-        print(f"variant {variant}: per-voxel {pv / tot:.3f}  free {fr / tot:.3f}  skipped {sk / tot:.3f}  ({tot} wavefront-frames)")
+        vol.sync()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            vol.integrate_frames_device(ptrs, poses)
+        vol.sync()
+        ms = (time.perf_counter() - t0) / (3 * n) * 1e3
+        print(f"  brick {shape:8s}: per-voxel {pv / tot:.4f}  free {fr / tot:.4f}  skipped {sk / tot:.4f}  "
+              f"({tot} wavefront-frames)  {ms:.4f} ms/frame", flush=True)
