@@ -327,7 +327,7 @@ size_t tile_table_elems_host(int tiles_w, int tiles_h)
     return (size_t)tile_levels_host(tiles_w) * tile_levels_host(tiles_h) * tiles_w * tiles_h;
 }
 
-bool tiles_fit(const tsdfk::IntegrateParams &p) { return (int64_t)p.tiles_w * p.tiles_h <= 8192; }
+bool tiles_fit(const tsdfk::IntegrateParams &p) { return (int64_t)p.tiles_w * p.tiles_h <= 16384; }
 
 // One-frame masked launches are classified per workgroup when the launch is large enough to repay the three small
 // dependent dispatches ahead of it (tile summary, sparse table, class table: ~25 us on the stream).  Measured

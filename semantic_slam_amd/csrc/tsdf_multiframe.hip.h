@@ -42,7 +42,11 @@ struct FramePose {
 // reference's depth-range test (0 < d <= max_depth, ref: src/tsdf.cu:46), else -inf; y = the largest depth among
 // the pixels that pass it, -inf if none does.  A NaN anywhere in the tile (NaN passes the reference's tests and
 // updates the voxel) makes the tile claim nothing: (-inf, +inf).
-constexpr int kTile = 16;
+#ifndef TSDF_TILE
+#define TSDF_TILE 16   /* pixels per tile edge: 16, or 8 for A/B builds (measured: the 4x larger tables cost more to build than their tighter ranges save -- 512^3 S-surf 0.0431 -> 0.0440 ms/frame, 16 x 200^3 masked 0.145 -> 0.277) */
+#endif
+constexpr int kTile = TSDF_TILE;
+static_assert(kTile == 8 || kTile == 16, "one wavefront per tile: 64 lanes x 1 or 4 pixels");
 
 // On top of the tiles a 2-D sparse table gives the same two quantities for ANY rectangle of tiles in four loads:
 // level (i, j) holds, at (ty, tx), the combination over the 2^i x 2^j tiles starting there (min of the x's, max of
@@ -67,7 +71,8 @@ __global__ __launch_bounds__(256) void depth_tile_summary(TileSummaryParams tp)
     if (tile >= tp.tiles_w * tp.tiles_h) return;
     const int ty = tile / tp.tiles_w, tx = tile - ty * tp.tiles_w;
     const int lane = threadIdx.x;
-    const int py = ty * kTile + (lane >> 2), px0 = tx * kTile + (lane & 3) * 4;
+    constexpr int kPxPerLane = kTile * kTile / 64, kLanesPerRow = kTile / kPxPerLane;
+    const int py = ty * kTile + lane / kLanesPerRow, px0 = tx * kTile + (lane % kLanesPerRow) * kPxPerLane;
     const float *d = tp.depth[f];
     const uint8_t *m = tp.mask[f];
     const float inf = __builtin_inff();
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(256) void depth_tile_summary(TileSummaryParams tp)
     bool all_valid = true, nan = false;
     if (py < tp.H) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < kPxPerLane; ++i) {
             const int px = px0 + i;
             if (px < tp.W) {
                 float v = d[(size_t)py * tp.W + px];
@@ -107,7 +112,7 @@ __global__ __launch_bounds__(256) void depth_tile_summary(TileSummaryParams tp)
 // from 2^i rows of it.  6 x n workgroups with one barrier each instead of one workgroup per frame walking through 29
 // dependent passes (55 us per launch: a third of a one-frame launch on a 200^3 volume).  Tables of more than
 // kTileLdsEntries tiles fall back to reading level (0, j) from memory after the barrier (same values).
-constexpr int kTileLdsEntries = 2048;   // float2: 2 x 16 KiB of LDS
+constexpr int kTileLdsEntries = kTile == 8 ? 5120 : 2048;   // float2: 2 x 40 KiB of LDS (a 640 x 480 frame has 4800 8-pixel tiles)
 
 __global__ __launch_bounds__(256) void tile_sparse_table(float2 *tables, int tw, int th)
 {
@@ -171,49 +176,50 @@ __global__ __launch_bounds__(256) void tile_sparse_table(float2 *tables, int tw,
 // cz >= cz_short) and cz_pad on the z bounds (twice the host's error bound on cz) cover the difference to the exact
 // per-voxel values, and rounding is monotone: d - cz >= trunc in the reals implies RN(d - cz) >= trunc.  A NaN or an
 // infinity in the corner arithmetic fails a comparison and yields 0.
+// PAIRED: the two half-waves share the work on a box of slices -- lane l and lane l ^ 32 are given the same frame and
+// the same rectangle, the lower one slice gz (the box's near slice), the upper one slice gz1 (its far slice); each
+// projects the four corners of its slice and the six extremes are combined across the halves (min and max are exact,
+// so the class is the one the eight-corner evaluation gives).  Every lane of the wavefront must make the call.
+template <bool PAIRED = false>
 __device__ __forceinline__ int classify_patch(const IntegrateParams &p, const FramePose *__restrict__ qp, const int xa,
                                               const int xb, const int ya, const int yb, const int gz, const int gz1 = -1)
 {
     const FramePose q = *qp;      // this lane's frame
-    if (q.tiles == nullptr) return 0;
-    const float dz = (p.oz + (float)gz * p.vs) - q.tz;
+    if constexpr (!PAIRED) { if (q.tiles == nullptr) return 0; }
     const float dxa = (p.ox + (float)xa * p.vs) - q.tx, dxb = (p.ox + (float)xb * p.vs) - q.tx;
     const float dya = (p.oy + (float)ya * p.vs) - q.ty, dyb = (p.oy + (float)yb * p.vs) - q.ty;
-    const float zx = q.rx2 * dz, zy = q.ry2 * dz, zz = q.rz2 * dz;
     const float inf = __builtin_inff();
     float umin = inf, umax = -inf, vmin = inf, vmax = -inf, czmin = inf, czmax = -inf;
     bool finite = true;
-    auto corner = [&](const float dx, const float dy) {
-        const float cx = q.rx0 * dx + q.rx1 * dy + zx;
-        const float cy = q.ry0 * dx + q.ry1 * dy + zy;
-        const float cz = q.rz0 * dx + q.rz1 * dy + zz;
-        const float inv = __builtin_amdgcn_rcpf(cz);
-        const float u = p.fx * (cx * inv) + p.cx, v = p.fy * (cy * inv) + p.cy;
-        umin = fminf(umin, u); umax = fmaxf(umax, u);
-        vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
-        czmin = fminf(czmin, cz); czmax = fmaxf(czmax, cz);
-        finite &= (u == u) & (v == v) & (cz == cz);     // fmin/fmax drop a NaN operand: keep it visible
-    };
-    corner(dxa, dya); corner(dxb, dya);
-    corner(dxa, dyb); corner(dxb, dyb);   // the same two again when ya == yb
-    if (gz1 > gz) {
-        // a box of slices gz .. gz1: camera-frame coordinates are affine in z too, so the far slice's corners complete
-        // the convex hull (and the z extremes)
-        const float dz1 = (p.oz + (float)gz1 * p.vs) - q.tz;
-        const float zx1 = q.rx2 * dz1, zy1 = q.ry2 * dz1, zz1 = q.rz2 * dz1;
-        auto corner1 = [&](const float dx, const float dy) {
-            const float cx = q.rx0 * dx + q.rx1 * dy + zx1;
-            const float cy = q.ry0 * dx + q.ry1 * dy + zy1;
-            const float cz = q.rz0 * dx + q.rz1 * dy + zz1;
+    // the four corners of one slice of the box: camera-frame coordinates are affine in x, y and z, so a box of slices
+    // gz .. gz1 projects into the convex hull of the corners of its near and far slice (and has its z extremes there)
+    auto slice_corners = [&](const int z) {
+        const float dz = (p.oz + (float)z * p.vs) - q.tz;
+        const float zx = q.rx2 * dz, zy = q.ry2 * dz, zz = q.rz2 * dz;
+        auto corner = [&](const float dx, const float dy) {
+            const float cx = q.rx0 * dx + q.rx1 * dy + zx;
+            const float cy = q.ry0 * dx + q.ry1 * dy + zy;
+            const float cz = q.rz0 * dx + q.rz1 * dy + zz;
             const float inv = __builtin_amdgcn_rcpf(cz);
             const float u = p.fx * (cx * inv) + p.cx, v = p.fy * (cy * inv) + p.cy;
             umin = fminf(umin, u); umax = fmaxf(umax, u);
             vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
             czmin = fminf(czmin, cz); czmax = fmaxf(czmax, cz);
-            finite &= (u == u) & (v == v) & (cz == cz);
+            finite &= (u == u) & (v == v) & (cz == cz);     // fmin/fmax drop a NaN operand: keep it visible
         };
-        corner1(dxa, dya); corner1(dxb, dya);
-        corner1(dxa, dyb); corner1(dxb, dyb);
+        corner(dxa, dya); corner(dxb, dya);
+        corner(dxa, dyb); corner(dxb, dyb);   // the same two again when ya == yb
+    };
+    if constexpr (PAIRED) {
+        slice_corners((threadIdx.x & 32u) ? max(gz1, gz) : gz);
+        umin = fminf(umin, __shfl_xor(umin, 32)); umax = fmaxf(umax, __shfl_xor(umax, 32));
+        vmin = fminf(vmin, __shfl_xor(vmin, 32)); vmax = fmaxf(vmax, __shfl_xor(vmax, 32));
+        czmin = fminf(czmin, __shfl_xor(czmin, 32)); czmax = fmaxf(czmax, __shfl_xor(czmax, 32));
+        finite = finite & (__shfl_xor((int)finite, 32) != 0);
+        if (q.tiles == nullptr) return 0;
+    } else {
+        slice_corners(gz);
+        if (gz1 > gz) slice_corners(gz1);
     }
     if (!(finite & (czmin > q.cz_short) & (czmax < 3.0e38f))) return 0;
     // pixel box that contains the rounded pixel of every voxel of the patch
@@ -857,10 +863,11 @@ __global__ __launch_bounds__(256, R == 2 ? 6 : (BRICK ? (LABELS ? 6 : TSDF_BRICK
             const int g = brick / p.bricks_per_group, i = brick - g * p.bricks_per_group;
             const int xa = i * p.brick_q * 4, ya = g * p.brick_r;
             const int z0 = wg_z * p.brick_s, z1 = min(z0 + p.brick_s - 1, p.nz - 1);
-            int cls = 0;
-            if (g < p.brick_groups && lane < mp.n_frames)
-                cls = classify_patch(p, s_frames + lane, xa, xa + p.brick_q * 4 - 1, ya, min(ya + p.brick_r - 1, p.dim_y - 1),
-                                     p.z_begin + z0, p.z_begin + z1);
+            // frame = lane mod 32; the half-waves share the box's near and far slice (classify_patch<PAIRED>)
+            static_assert(kMaxFramesPerLaunch == 32, "one frame per lane of a half-wave");
+            int cls = classify_patch<true>(p, s_frames + (lane & 31), xa, xa + p.brick_q * 4 - 1, ya,
+                                           min(ya + p.brick_r - 1, p.dim_y - 1), p.z_begin + z0, p.z_begin + z1);
+            if (g >= p.brick_groups || lane >= mp.n_frames) cls = 0;
             const unsigned long long fb = __ballot(cls == 1), sb = __ballot(cls == 2);
             free_frames = (unsigned int)fb;
             skip_frames = (unsigned int)sb;

@@ -1,8 +1,11 @@
-# brick shapes (TSDF_BRICK3D="q,r,s") with the rotated slice order, classification by policy
+# fused-path numbers at the library's own brick choice
 one() { python bench.py "$@" --no-extras --no-traffic --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'])"; }
-for shape in 2,4,8 2,8,4 2,2,16 1,8,8 1,4,16 4,2,8 4,1,16 2,1,32; do
-  echo "shape $shape: ssurf512 $(TSDF_BRICK3D=$shape one --workload ssurf --grid 512)  traj1024 $(TSDF_BRICK3D=$shape one --workload traj --grid 1024)  ssurf200@4mm $(TSDF_BRICK3D=$shape one --workload ssurf --grid 200 --voxel-mm 4)"
-done
-for shape in 5,12,1 2,4,8 5,3,4 2,2,16 1,8,8; do
-  echo "16 x 200^3 instance masks, shape $shape:"; TSDF_BRICK3D=$shape python tools/batch_time.py --n 16 2>&1 | grep "batched launch, classification by policy (bricks)\|per-volume launches, classification by policy"
-done
+echo "ssurf 512: $(one --workload ssurf)"
+echo "traj 1024: $(one --workload traj)"
+echo "ssurf 384: $(one --workload ssurf --grid 384)"
+echo "ssurf 200: $(one --workload ssurf --grid 200)"
+echo "ssurf 200 @ 4 mm: $(one --workload ssurf --grid 200 --voxel-mm 4)"
+echo "sfull 512 fused: $(one --workload sfull --mode fused)"
+echo "sband 512 fused: $(one --workload sband --mode fused)"
+python tools/batch_time.py --n 16 2>&1 | grep -v amdgpu
+python tools/batch_time.py --n 2 --edge 400 2>&1 | grep -v amdgpu
