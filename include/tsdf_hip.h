@@ -410,10 +410,17 @@ int tsdf_object_origin(int32_t device, const float *depth_dev, const uint8_t *ma
  * Batched per-object fusion: the reference keeps one small TSDF per object instance and feeds
  * each of them depth * (its instance mask) for every keyframe (ref: src/Engine.cpp:172-233,
  * src/Object.cpp:67,143-166).  A batch owns n volumes (own grid, origin and base pose each; same
- * device and image size; dim_x % 4 == 0) and integrates one frame into ALL of them with one
- * kernel launch.  masks_dev: n device pointers to im_height*im_width {0,255} bytes (entry or
- * whole array may be NULL = unmasked).  Volumes are borrowed with tsdf_batch_volume() for
- * download / save / extraction; they are destroyed with the batch.
+ * device and image size; dim_x % 4 == 0) and integrates one frame into ALL of them per call.
+ * masks_dev: n device pointers to im_height*im_width {0,255} bytes (entry or whole array may be
+ * NULL = unmasked).  Volumes are borrowed with tsdf_batch_volume() for download / save /
+ * extraction; they are destroyed with the batch.
+ * How the frames reach the volumes is the library's choice, the result is the same bits: either one
+ * kernel launch over all members per call, or -- deferral, the default for batches of few or large
+ * members, as for a single handle (tsdf_set_deferral on the FIRST member sets the frames per flush, 0 / 1
+ * switches it off) -- the frame is copied into the batch's pool in HBM (the depth image once, the masks
+ * by one gather launch; the caller's buffers are free again under the batch stream's order) and every
+ * 32 collected frames are applied by one fused launch per member.  tsdf_batch_sync and every call that
+ * observes or integrates into a member through its borrowed handle apply the collected frames first.
  */
 typedef struct tsdf_batch tsdf_batch;
 int tsdf_batch_create(const tsdf_config *cfgs, int32_t n, tsdf_batch **out);

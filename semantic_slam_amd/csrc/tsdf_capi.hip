@@ -86,6 +86,7 @@ struct tsdf_volume {
     bool pool_used[2];
     hipEvent_t pend_copied;
     int pool_cur, pend_count;
+    struct tsdf_batch *owner;   // the batch this handle is a member of (its collected frames come first), or null
     bool in_flush;
     float pend_c2b[16 * tsdfk::kMaxFramesPerLaunch];
     uint8_t *d_mask_pool[2];          // instance masks of collected masked frames (allocated on first use)
@@ -158,17 +159,32 @@ struct tsdf_batch {
     uint8_t *d_wg_class;
     uint8_t *d_brick_class;      // class per wavefront brick of the launch (classify_bricks_batched), on first use
     size_t brick_class_bytes;
+    // Deferred integration of a batch of large members (tsdf_batch_integrate_device): frames are collected in HBM -- the
+    // depth image once, every member's mask beside it -- and applied by ONE fused launch per member per 32 frames
+    // (the volume then moves once per 32 frames instead of once per frame); flushed by anything that observes a member.
+    float *d_depth_pool;                     // kMaxFramesPerLaunch frames
+    uint8_t *d_mask_pool;                    // kMaxFramesPerLaunch x members masks
+    std::vector<float> pend_c2b;             // [member][frame][16], composed at collection time
+    std::vector<const uint8_t *> pend_mask;  // [member][frame], null = the member's frame has no mask
+    int pend_count;
+    bool in_flush;
 };
 
 namespace {
 
 int flush_pending(tsdf_volume *v);
+int batch_flush(tsdf_batch *b);
+int batch_collect(tsdf_batch *b, const float *depth_dev, const uint8_t *const *masks_dev, const float cam2world[16]);
 
 // Every entry point starts here: make the handle's device current and, unless the caller is the collecting call itself,
 // apply the host frames tsdf_integrate has collected (deferred integration, see struct tsdf_volume).
 int bind_device(tsdf_volume *v, bool flush = true)
 {
     HIP_TRY(hipSetDevice(v->cfg.device));
+    if (v->owner && !v->in_flush) {   // frames its batch has collected were given first
+        int rc = batch_flush(v->owner);
+        if (rc) return rc;
+    }
     if (flush && v->pend_count > 0 && !v->in_flush) return flush_pending(v);
     return TSDF_OK;
 }
@@ -1895,13 +1911,89 @@ int tsdf_download_colour(tsdf_volume *v, uint32_t *colour_host)
 // ---------------------------------------------------------------------------------------------
 // batched per-object volumes
 // ---------------------------------------------------------------------------------------------
+namespace {
+
+
+// Apply the frames the batch has collected: one fused launch per member, in member order, on the batch's stream.
+int batch_flush(tsdf_batch *b)
+{
+    if (b->pend_count == 0 || b->in_flush) return TSDF_OK;
+    b->in_flush = true;
+    const int n = b->pend_count, members = (int)b->vols.size();
+    b->pend_count = 0;
+    const size_t px = (size_t)b->vols[0]->cfg.im_height * b->vols[0]->cfg.im_width;
+    const float *ptrs[tsdfk::kMaxFramesPerLaunch];
+    for (int f = 0; f < n; ++f) ptrs[f] = b->d_depth_pool + (size_t)f * px;
+    int rc = TSDF_OK;
+    if (hipSetDevice(b->device) != hipSuccess) rc = fail(TSDF_ERR_HIP, "tsdf_batch: hipSetDevice failed");
+    for (int i = 0; i < members && rc == TSDF_OK; ++i) {
+        tsdf_volume *v = b->vols[i];
+        const uint8_t *const *masks = b->pend_mask.data() + (size_t)i * tsdfk::kMaxFramesPerLaunch;
+        const float *c2b = b->pend_c2b.data() + (size_t)i * tsdfk::kMaxFramesPerLaunch * 16;
+        bool any_mask = false;
+        for (int f = 0; f < n; ++f) any_mask = any_mask || masks[f] != nullptr;
+        if (can_fuse(v) && n > 1) {
+            rc = launch_multi(v, ptrs, any_mask ? masks : nullptr, c2b, n);
+        } else {
+            for (int f = 0; f < n && rc == TSDF_OK; ++f) rc = launch_integrate(v, ptrs[f], masks[f], c2b + 16 * f);
+        }
+    }
+    b->in_flush = false;
+    return rc;
+}
+
+// Collect one frame for every member: the depth image once, the masks by one gather launch, the poses composed now.
+// Everything is queued on the batch's stream, so the caller's buffers are free for reuse under that stream's order and the
+// pool is not overwritten before the launches that read it have run.
+int batch_collect(tsdf_batch *b, const float *depth_dev, const uint8_t *const *masks_dev, const float cam2world[16])
+{
+    const int members = (int)b->vols.size(), slot = b->pend_count;
+    const size_t px = (size_t)b->vols[0]->cfg.im_height * b->vols[0]->cfg.im_width;
+    if (!b->d_depth_pool) {
+        HIP_TRY(hipMalloc((void **)&b->d_depth_pool, (size_t)tsdfk::kMaxFramesPerLaunch * px * sizeof(float)));
+        b->pend_c2b.assign((size_t)members * tsdfk::kMaxFramesPerLaunch * 16, 0.0f);
+        b->pend_mask.assign((size_t)members * tsdfk::kMaxFramesPerLaunch, nullptr);
+    }
+    bool any_mask = false;
+    for (int i = 0; i < members && masks_dev; ++i) any_mask = any_mask || masks_dev[i] != nullptr;
+    if (any_mask && !b->d_mask_pool)
+        HIP_TRY(hipMalloc((void **)&b->d_mask_pool, (size_t)tsdfk::kMaxFramesPerLaunch * members * px));
+    HIP_TRY(hipMemcpyAsync(b->d_depth_pool + (size_t)slot * px, depth_dev, px * sizeof(float), hipMemcpyDeviceToDevice, b->stream));
+    for (int i0 = 0; i0 < members && any_mask; i0 += tsdfk::kGatherMasks) {
+        tsdfk::MaskGatherParams gp;
+        const int m = std::min(tsdfk::kGatherMasks, members - i0);
+        bool some = false;
+        for (int k = 0; k < tsdfk::kGatherMasks; ++k) {
+            gp.src[k] = k < m ? masks_dev[i0 + k] : nullptr;
+            gp.dst[k] = k < m ? b->d_mask_pool + ((size_t)slot * members + i0 + k) * px : nullptr;
+            some = some || gp.src[k] != nullptr;
+        }
+        gp.bytes = px;
+        if (some) hipLaunchKernelGGL(tsdfk::gather_masks, dim3((unsigned)((px + 4095) / 4096), (unsigned)m), dim3(256), 0, b->stream, gp);
+    }
+    HIP_TRY(hipGetLastError());
+    for (int i = 0; i < members; ++i) {
+        tsdf_volume *v = b->vols[i];
+        float *c2b = b->pend_c2b.data() + ((size_t)i * tsdfk::kMaxFramesPerLaunch + slot) * 16;
+        compose_cam2base(v, cam2world, c2b);   // each object has its own base frame (ref: src/Object.cpp:23-29)
+        std::memcpy(v->last_cam2base, c2b, 16 * sizeof(float));
+        b->pend_mask[(size_t)i * tsdfk::kMaxFramesPerLaunch + slot] =
+            (masks_dev && masks_dev[i]) ? b->d_mask_pool + ((size_t)slot * members + i) * px : nullptr;
+    }
+    b->pend_count = slot + 1;
+    if (b->pend_count >= std::min(b->vols[0]->defer_n, (int)tsdfk::kMaxFramesPerLaunch)) return batch_flush(b);
+    return TSDF_OK;
+}
+
+}  // namespace
+
 int tsdf_batch_destroy(tsdf_batch *b)
 {
     if (!b) return TSDF_OK;
     (void)hipSetDevice(b->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     for (tsdf_volume *v : b->vols) {
-        if (v) { v->stream = v->own_stream; tsdf_destroy(v); }
+        if (v) { v->stream = v->own_stream; v->owner = nullptr; tsdf_destroy(v); }
     }
     for (int i = 0; i < kStageSlots; ++i) {
         if (b->h_params[i]) (void)hipHostFree(b->h_params[i]);
@@ -1915,6 +2007,8 @@ int tsdf_batch_destroy(tsdf_batch *b)
     if (b->d_tiles) (void)hipFree(b->d_tiles);
     if (b->d_wg_class) (void)hipFree(b->d_wg_class);
     if (b->d_brick_class) (void)hipFree(b->d_brick_class);
+    if (b->d_depth_pool) (void)hipFree(b->d_depth_pool);
+    if (b->d_mask_pool) (void)hipFree(b->d_mask_pool);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
     return TSDF_OK;
@@ -1935,6 +2029,7 @@ int tsdf_batch_create(const tsdf_config *cfgs, int32_t n, tsdf_batch **out)
     if (!b) return fail(TSDF_ERR_INVALID, "tsdf_batch_create: out of host memory");
     b->device = cfgs[0].device;
     b->stream = nullptr; b->d_slice_map = nullptr; b->d_group_map = nullptr; b->total_groups = 0; b->slot_next = 0;
+    b->d_depth_pool = nullptr; b->d_mask_pool = nullptr; b->pend_count = 0; b->in_flush = false;
     b->d_tiles = nullptr; b->tiles_per_object = 0; b->d_wg_class = nullptr; b->d_brick_class = nullptr; b->brick_class_bytes = 0;
     b->total_slices = b->max_blocks = 0;
     for (int i = 0; i < kStageSlots; ++i) {
@@ -1969,6 +2064,7 @@ int tsdf_batch_create(const tsdf_config *cfgs, int32_t n, tsdf_batch **out)
     for (tsdf_volume *v : b->vols) {   // creation fills ran on each volume's own stream: finish them, then share ours
         if (hipStreamSynchronize(v->stream) != hipSuccess) return cleanup(fail(TSDF_ERR_HIP, "tsdf_batch_create: sync failed"));
         v->stream = b->stream;
+        v->owner = b;
     }
     *out = b;
     return TSDF_OK;
@@ -1987,6 +2083,8 @@ int tsdf_batch_sync(tsdf_batch *b)
 {
     if (!b) return fail(TSDF_ERR_INVALID, "tsdf_batch_sync: NULL handle");
     HIP_TRY(hipSetDevice(b->device));
+    int rc = batch_flush(b);
+    if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(b->stream));
     return TSDF_OK;
 }
@@ -1997,13 +2095,29 @@ int tsdf_batch_integrate_device(tsdf_batch *b, const float *depth_dev, const uin
     if (!b || !depth_dev || !cam2world) return fail(TSDF_ERR_INVALID, "tsdf_batch_integrate_device: NULL argument");
     HIP_TRY(hipSetDevice(b->device));
     if (b->total_slices == 0) return TSDF_OK;
+    const int n = (int)b->vols.size();
+    for (tsdf_volume *v : b->vols)
+        if (v->pend_count > 0) { int rc = flush_pending(v); if (rc) return rc; }   // frames given to a borrowed handle come first
+    // Deferral as for a single handle (tsdf_set_deferral on the FIRST member switches it): collect the frame and apply 32 at
+    // a time with one fused launch per member -- the volumes then move once per 32 frames, but every member costs a launch
+    // with its own tile tables per flush, so many small members stay with the one batched launch per frame.  Fitted to
+    // tools/batch_time.py (instance masks, ms per frame, batched -> deferred): 1 x 200^3 0.035 -> 0.013, 4 x 200^3 0.082
+    // -> 0.031, 16 x 200^3 0.145 -> 0.100, 2 x 400^3 0.122 -> 0.046, 8 x 128^3 0.059 -> 0.047; but 16 x 64^3 0.035 ->
+    // 0.070, 64 x 100^3 0.229 -> 0.307: deferred costs about 4 us per member + 0.8 us per M voxels, batched 20 us + 2.8.
+    {
+        bool defer = b->vols[0]->defer_n > 1;
+        int64_t total = 0;
+        for (tsdf_volume *v : b->vols) { defer = defer && can_fuse(v); total += v->n_vox; }
+        defer = defer && 2 * (int64_t)n < 10 + total / 1000000;
+        if (defer) return batch_collect(b, depth_dev, masks_dev, cam2world);
+        int rc = batch_flush(b);   // the policy changed between calls (tsdf_set_deferral, a kernel variant)
+        if (rc) return rc;
+    }
     const int s = b->slot_next;
     b->slot_next = (s + 1) % kStageSlots;
     if (b->slot_used[s]) HIP_TRY(hipEventSynchronize(b->slot_done[s]));
-    const int n = (int)b->vols.size();
     for (int i = 0; i < n; ++i) {
         tsdf_volume *v = b->vols[i];
-        if (v->pend_count > 0) { int rc = flush_pending(v); if (rc) return rc; }   // frames given to a borrowed handle come first
         float c2b[16];
         compose_cam2base(v, cam2world, c2b);   // each object has its own base frame (ref: src/Object.cpp:23-29)
         std::memcpy(v->last_cam2base, c2b, sizeof c2b);

@@ -976,4 +976,26 @@ __global__ __launch_bounds__(256, 8) void integrate_multi_batched_bricks(const I
     multi_body<1, NT, false, false, true, true, true>(p, poses + m.x, 1, blockIdx.x, 0, m.y, LabelState(), c == 1u ? 1u : 0u, 0u);
 }
 
+// The instance masks of one frame for up to kGatherMasks objects, copied into a batch's frame pool by ONE launch
+// (tsdf_batch_integrate_device, deferred): grid = (chunks of 4 KiB, objects); a null source is skipped.
+constexpr int kGatherMasks = 32;
+struct MaskGatherParams {
+    const uint8_t *src[kGatherMasks];
+    uint8_t *dst[kGatherMasks];
+    size_t bytes;      // per mask
+};
+
+__global__ __launch_bounds__(256) void gather_masks(MaskGatherParams gp)
+{
+    const uint8_t *src = gp.src[blockIdx.y];
+    uint8_t *dst = gp.dst[blockIdx.y];
+    if (src == nullptr) return;
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    if (i + 16 <= gp.bytes && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+        *reinterpret_cast<uint4 *>(dst + i) = *reinterpret_cast<const uint4 *>(src + i);
+    } else {
+        for (size_t k = i; k < gp.bytes && k < i + 16; ++k) dst[k] = src[k];
+    }
+}
+
 }  // namespace tsdfk

@@ -9,7 +9,8 @@ from semantic_slam_amd import capi, synth
 pytestmark = pytest.mark.gpu
 
 
-def test_batch_matches_per_object_oracle(cuda, oracle):
+@pytest.mark.parametrize("deferred", [False, True])   # one batched launch per frame / frames collected, one fused launch per member
+def test_batch_matches_per_object_oracle(cuda, oracle, deferred):
     rng = np.random.default_rng(42)
     specs = [  # dims, voxel size, grid origin (base frame), mask rectangle or None
         ((200, 200, 200), 0.004, (-0.40, -0.40, 0.70), (60, 420, 80, 560)),   # the reference's default grid
@@ -32,13 +33,18 @@ def test_batch_matches_per_object_oracle(cuda, oracle):
             masks.append(m)
     refs = [oracle.init_grid(d) for d, _, _, _ in specs]
     with capi.Batch(cfgs) as batch:
+        if not deferred:
+            batch.volumes[0].set_deferral(0)
         m_dev = [None if m is None else cuda.from_numpy(m).cuda() for m in masks]
+        keep = []
         for k in range(3):
             c2w = scene.pose(k, n=6)
             depth = scene.depth(c2w, quantize=True)
             d_dev = cuda.from_numpy(depth).cuda()
+            keep.append(d_dev)
             batch.integrate_device(d_dev.data_ptr(), [None if t is None else t.data_ptr() for t in m_dev], c2w)
-            batch.sync()
+            if not deferred:
+                batch.sync()
             for (d, vs, o, _), b, m, (rt, rw), cfg in zip(specs, bases, masks, refs, cfgs):
                 dm = depth if m is None else oracle.mask_depth(depth, m)
                 oracle.integrate(cfg.cam_K, oracle.cam2base(b, c2w), dm, d, np.array(o, np.float32), vs,
@@ -108,13 +114,17 @@ def test_object_origin_negative_zero_and_stream_order(cuda, oracle):
         assert np.array_equal(got2.view(np.uint32), want2.view(np.uint32)) and want2[2] == np.float32(1.5)
 
 
+@pytest.mark.parametrize("deferred", [False, True])
 @pytest.mark.parametrize("classified", [True, False])
-def test_instance_masked_object_volumes_skip_exactly(cuda, oracle, classified):
+def test_instance_masked_object_volumes_skip_exactly(cuda, oracle, classified, deferred):
     """The reference's call shape at its own grid size: 200^3 @ 4 mm object volumes, each fed depth x its instance mask,
     one frame per call -- batched launch and per-volume tsdf_integrate_masked_device.  With the per-workgroup
     classification (default) the workgroups outside an instance leave at once; results must not depend on it (variant 7
     switches it off) and must equal the oracle bit for bit.  One frame carries +inf outside the masks: inf x 0 = NaN,
-    which DOES update a voxel (ref: src/tsdf.cu:46,49), so those tiles may claim nothing."""
+    which DOES update a voxel (ref: src/tsdf.cu:46,49), so those tiles may claim nothing.
+    deferred (the default for members of >= 4 M voxels): the batch collects the frames -- the depth once, the masks by one
+    gather launch -- and applies them with one fused launch per member when it is observed; not deferred: one batched
+    launch per frame."""
     rng = np.random.default_rng(21)
     dims, vs = (200, 200, 200), 0.004
     K = synth.TUM_K
@@ -144,7 +154,10 @@ def test_instance_masked_object_volumes_skip_exactly(cuda, oracle, classified):
     m_dev = [cuda.from_numpy(m).cuda() for _, m in objs]
     d_dev = [cuda.from_numpy(d).cuda() for _, d in frames]
     with capi.Batch(cfgs) as batch:
-        batch.volumes[0].set_kernel_variant(8 if classified else 7)   # 8: classify whatever the launch size
+        for vol in batch.volumes:
+            vol.set_kernel_variant(8 if classified else 7)   # 8: classify whatever the launch size (batched launch: the first member's)
+        if not deferred:
+            batch.volumes[0].set_deferral(0)
         for (pose, _), d in zip(frames, d_dev):
             batch.integrate_device(d.data_ptr(), [m.data_ptr() for m in m_dev], pose)
         batch.sync()

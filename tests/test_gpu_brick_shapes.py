@@ -84,7 +84,8 @@ def test_single_masked_frames_do_not_depend_on_the_brick_shape(cuda, oracle, dim
         assert np.array_equal(t.view(np.uint32), ref_t.view(np.uint32)), f"{shape}: TSDF differs"
 
 
-def test_batched_objects_with_their_own_brick_shapes(cuda, oracle):
+@pytest.mark.parametrize("deferred", [False, True])   # one batched launch per frame (group map) / one fused launch per member
+def test_batched_objects_with_their_own_brick_shapes(cuda, oracle, deferred):
     """Every member of a batch brings its own brick (and its own number of slice groups); changing a member's shape
     between frames rebuilds the launch's group map."""
     rng = np.random.default_rng(11)
@@ -105,10 +106,13 @@ def test_batched_objects_with_their_own_brick_shapes(cuda, oracle):
         masks.append(m)
     refs = [oracle.init_grid(d) for d, _, _, _ in specs]
     with capi.Batch(cfgs) as batch:
-        batch.volumes[0].set_kernel_variant(8)
         for vol, (_, _, _, shape) in zip(batch.volumes, specs):
+            vol.set_kernel_variant(8)
             vol.set_brick_shape(*shape)
+        if not deferred:
+            batch.volumes[0].set_deferral(0)
         m_dev = [cuda.from_numpy(m).cuda() for m in masks]
+        keep = []
         for k in range(4):
             if k == 2:                          # new shapes mid-sequence
                 batch.volumes[0].set_brick_shape(5, 6, 2)
@@ -116,8 +120,10 @@ def test_batched_objects_with_their_own_brick_shapes(cuda, oracle):
             c2w = scene.pose(k, n=6)
             depth = scene.depth(c2w, quantize=True)
             d_dev = cuda.from_numpy(depth).cuda()
+            keep.append(d_dev)
             batch.integrate_device(d_dev.data_ptr(), [t.data_ptr() for t in m_dev], c2w)
-            batch.sync()
+            if not deferred:
+                batch.sync()
             for (d, vs, o, _), m, (rt, rw), cfg in zip(specs, masks, refs, cfgs):
                 oracle.integrate(cfg.cam_K, c2w, oracle.mask_depth(depth, m), d, np.array(o, np.float32), vs, cfg.trunc_margin, rt, rw)
         for vol, (rt, rw) in zip(batch.volumes, refs):

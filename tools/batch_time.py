@@ -51,9 +51,11 @@ cover = float(np.mean([m.mean() / 255.0 for m in masks]))
 vox = n * E ** 3
 print(f"{n} volumes of {E}^3, masks: {args.masks} (mean coverage {cover:.2f} of the image)")
 NAMES = {0: "by policy (bricks)        ", 8: "forced on (bricks)        ", 11: "by policy (1024-voxel patches)", 7: "off                       "}
-for cls in (0, 8, 11, 7):
+for cls, deferral in ((0, 32), (0, 0), (8, 0), (11, 0), (7, 0)):
     with capi.Batch(cfgs) as batch:
-        batch.volumes[0].set_kernel_variant(cls)
+        for v in batch.volumes:
+            v.set_kernel_variant(cls)
+        batch.volumes[0].set_deferral(deferral)   # 32: few / large members collect frames and fuse 32 per launch (the default)
         for k in range(10):
             batch.integrate_device(depth.data_ptr(), ptrs, poses[k % 8])
         batch.sync()
@@ -63,7 +65,8 @@ for cls in (0, 8, 11, 7):
         batch.sync()
         tb = (time.perf_counter() - t0) / frames
         upd = sum(float(v.download()[1].sum()) for v in batch.volumes) / (frames + 10)
-    print(f"  batched launch, classification {NAMES[cls]}: {tb * 1e3:.3f} ms/frame ({vox / tb / 1e6:.0f} Mvox/s), "
+    how = "batch, deferral by policy        " if deferral else "batched launch per frame         "
+    print(f"  {how}, classification {NAMES[cls]}: {tb * 1e3:.3f} ms/frame ({vox / tb / 1e6:.0f} Mvox/s), "
           f"{upd / vox:.3f} of the voxels updated per frame", flush=True)
 for cls in (0, 8, 7):
     vols = [capi.Volume(c) for c in cfgs]
