@@ -114,6 +114,8 @@ struct tsdf_volume {
     bool flat;             // dim_x % 256 != 0: summary-maintaining launches use the flat mapping
     int brick_q, brick_r, brick_s;   // wavefront brick of the classified launches (choose_brick / tsdf_set_brick_shape); q = 0: none
     bool flags_known_zero;
+    unsigned int *d_super;       // per super-brick frame words of the current fused brick launch (classify_superbricks)
+    size_t super_words;
     // depth tile summaries of the frames of one fused launch (allocated on first use), optional counters
     float2 *d_tiles;
     unsigned int *d_shortcut_stats;
@@ -355,7 +357,7 @@ constexpr int64_t kClassifyMinVoxels = 48000000;
 bool classify_one_frame(const tsdf_volume *v, int64_t launch_voxels)
 {
     if (v->variant == 7) return false;
-    return v->variant == 8 || launch_voxels >= kClassifyMinVoxels;
+    return v->variant == 8 || v->variant == 12 || launch_voxels >= kClassifyMinVoxels;
 }
 
 // Depth tile tables (summary + sparse table, tsdf_multiframe.hip.h) of n images depth[i] x mask[i] into tables[i], queued
@@ -506,7 +508,7 @@ int launch_integrate(tsdf_volume *v, const float *depth_dev, const uint8_t *mask
     if (nz == 0) return TSDF_OK;  // empty slab: nothing to do
     std::memcpy(v->last_cam2base, c2b, sizeof v->last_cam2base);
     int variant = v->variant;
-    if (variant == 0 || (variant >= 3 && variant <= 11)) variant = kDefaultTile;
+    if (variant == 0 || (variant >= 3 && variant <= 12)) variant = kDefaultTile;
     if (c.dim_x % 4 != 0) variant = 1;  // rows are not 16-byte aligned: scalar kernel
     if (v->flat && variant != 1 && variant != 2) {
         // rows that are not a multiple of 256 voxels: the flat mapping (every lane busy, summary kept)
@@ -690,7 +692,7 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
             // label launches classify only through bricks (a claimed wavefront-frame carries no label evidence either:
             // skipped = not observed, free space = outside the truncation band)
             if (label_ims && (mi.common.brick_q == 0 || v->variant == 11)) classify = false;
-            if (classify && v->variant != 8 && v->variant != 11)
+            if (classify && v->variant != 8 && v->variant != 11 && v->variant != 12)
                 classify = !v->claims_known || v->claim_fraction >= 0.10 || v->launches_unclassified >= 7;
             v->launches_unclassified = classify ? 0 : v->launches_unclassified + 1;
             const bool count_claims = classify && !v->claims_pending;
@@ -721,6 +723,22 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
                 const unsigned wgs = (unsigned)(((int64_t)mi.common.brick_groups * mi.common.bricks_per_group + 3) / 4);
                 if (wgs > 65535u) mi.z_fastest = 0;   // the slow grid dimensions hold 65535 at most
                 grid_bricks = mi.z_fastest ? dim3((unsigned)nz_groups, 1, wgs) : dim3(wgs, 1, (unsigned)nz_groups);
+            }
+            mi.super_mask = nullptr;
+            mi.nz_super = 1;
+            if (bricks && v->variant != 12) {   // variant 12: bricks without the super-brick pre-pass (A/B)
+                const unsigned wgs = (unsigned)(((int64_t)mi.common.brick_groups * mi.common.bricks_per_group + 3) / 4);
+                mi.nz_super = (nz_groups + tsdfk::kSuperZ - 1) / tsdfk::kSuperZ;
+                const size_t words = (size_t)wgs * mi.nz_super;
+                if (v->super_words < words) {
+                    if (v->d_super) HIP_TRY(hipFree(v->d_super));
+                    v->d_super = nullptr;
+                    v->super_words = 0;
+                    HIP_TRY(hipMalloc((void **)&v->d_super, words * sizeof(unsigned int)));
+                    v->super_words = words;
+                }
+                hipLaunchKernelGGL(tsdfk::classify_superbricks, dim3((unsigned)((words + 3) / 4)), block, 0, v->stream, mi, v->d_super, (int)wgs);
+                mi.super_mask = v->d_super;
             }
             if (bricks && label_ims)
                 hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, true, false, true, true>), grid_bricks, block, 0, v->stream, mi);
@@ -805,7 +823,7 @@ int frames_per_launch(const tsdf_volume *)
 
 bool can_fuse(const tsdf_volume *v)
 {
-    return (v->variant == 0 || (v->variant >= 4 && v->variant <= 11)) && v->cfg.dim_x % 4 == 0;
+    return (v->variant == 0 || (v->variant >= 4 && v->variant <= 12)) && v->cfg.dim_x % 4 == 0;
 }
 
 // A sequence of frames: fused frames_per_launch() at a time when the default kernel is selected.
@@ -1159,6 +1177,7 @@ int tsdf_destroy(tsdf_volume *v)
     if (v->d_wg_class) (void)hipFree(v->d_wg_class);
     if (v->d_flags) (void)hipFree(v->d_flags);
     if (v->d_tiles) (void)hipFree(v->d_tiles);
+    if (v->d_super) (void)hipFree(v->d_super);
     if (v->d_claims) (void)hipFree(v->d_claims);
     if (v->h_claims) (void)hipHostFree(v->h_claims);
     if (v->claims_done) (void)hipEventDestroy(v->claims_done);
@@ -1468,7 +1487,7 @@ int tsdf_classification_info(tsdf_volume *v, double info_out[2])
 int32_t tsdf_frames_per_launch(const tsdf_volume *v)
 {
     if (!v) return 0;
-    const bool fuse = (v->variant == 0 || (v->variant >= 4 && v->variant <= 11)) && v->cfg.dim_x % 4 == 0;
+    const bool fuse = (v->variant == 0 || (v->variant >= 4 && v->variant <= 12)) && v->cfg.dim_x % 4 == 0;
     return fuse ? frames_per_launch(v) : 1;
 }
 
@@ -1508,7 +1527,7 @@ int tsdf_set_kernel_variant(tsdf_volume *v, int32_t variant)
     if (!v) return fail(TSDF_ERR_INVALID, "tsdf_set_kernel_variant: NULL handle");
     const int c = (variant - 32) & 15;
     const bool sum_ok = (variant >= 32 && variant < 112 && c < 12 && ((c >> 1) & 1)) || variant == 115 || variant == 119;
-    if (!(variant >= 0 && variant <= 11) && !(variant >= 16 && variant < 28) && !sum_ok)
+    if (!(variant >= 0 && variant <= 12) && !(variant >= 16 && variant < 28) && !sum_ok)
         return fail(TSDF_ERR_INVALID, "tsdf_set_kernel_variant: unknown variant %d", variant);
     v->variant = variant;
     return TSDF_OK;
@@ -2136,7 +2155,7 @@ int tsdf_batch_integrate_device(tsdf_batch *b, const float *depth_dev, const uin
     int64_t launch_voxels = 0;
     for (tsdf_volume *v : b->vols) launch_voxels += v->n_vox;
     // ... and not for many small volumes: one tile table per object has to be built per frame (64 x 100^3: 0.231 -> 0.262 ms)
-    const bool big_enough = b->vols[0]->variant == 8 || launch_voxels >= (int64_t)n * 2000000;
+    const bool big_enough = b->vols[0]->variant == 8 || b->vols[0]->variant == 12 || launch_voxels >= (int64_t)n * 2000000;
     const bool classify = any_mask && same_range && big_enough && classify_one_frame(b->vols[0], launch_voxels) &&
                           tiles_fit(b->h_params[s][0]);
     if (classify) {

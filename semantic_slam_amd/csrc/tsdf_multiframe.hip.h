@@ -369,7 +369,14 @@ struct MultiParamsInline {
     // index, so with a slice count that is a multiple of 8 order 1 gives every slice to ONE XCD -- and a surface that
     // lies across few slices (a wall facing the camera) then keeps one or two XCDs busy while the others idle
     int z_fastest;
+    // BRICK launches: per super-brick (a workgroup's four bricks x kSuperZ consecutive slice groups) the frames that may
+    // do something to it (classify_superbricks); a workgroup whose word is 0 leaves before it stages or classifies
+    // anything.  Null: no such table.  Index = workgroup index within the slice group * nz_super + slice group / kSuperZ.
+    const unsigned int *super_mask;
+    int nz_super;
 };
+
+constexpr int kSuperZ = 4;
 
 // FLAT: the lane's quad comes from the linear view of the slice (IntegrateParams::quads_per_slice):
 // wavefront = 64 consecutive quads in memory order, whatever dim_x % 4 == 0 is -- rows shorter than or
@@ -810,6 +817,18 @@ __global__ __launch_bounds__(256, R == 2 ? 6 : (BRICK ? (LABELS ? 6 : TSDF_BRICK
         wg_z += (int)((unsigned)(wg_x + wg_y) % gridDim.x);
         if (wg_z >= (int)gridDim.x) wg_z -= (int)gridDim.x;
     }
+    if constexpr (BRICK) {
+        if (mp.super_mask != nullptr && mp.super_mask[(size_t)wg_x * mp.nz_super + wg_z / kSuperZ] == 0u) {
+            // every frame skips the whole super-brick: the workgroup's wavefront-frames are all "skipped" claims
+            const IntegrateParams &p = mp.common;
+            if ((p.claim_counter != nullptr || p.shortcut_stats != nullptr) && threadIdx.x == 0 && threadIdx.y == 0) {
+                const int in_range = max(0, min(4, p.brick_groups * p.bricks_per_group - wg_x * 4));
+                if (p.claim_counter != nullptr) atomicAdd(p.claim_counter, (unsigned long long)(in_range * mp.n_frames));
+                if (p.shortcut_stats != nullptr) atomicAdd(p.shortcut_stats + 2, (unsigned)(in_range * mp.n_frames));
+            }
+            return;
+        }
+    }
     if constexpr (SHORT) {
         // Patch classification in the prologue.  The first wavefront stages the frame blocks in LDS (coalesced); then
         //   row / flat mapping: it classifies the workgroup's patch (256 x 4 voxels, or 1024 consecutive ones), one frame
@@ -891,6 +910,40 @@ __global__ __launch_bounds__(256, R == 2 ? 6 : (BRICK ? (LABELS ? 6 : TSDF_BRICK
     }
     multi_body<R, NT, FLAT, LABELS, MASKS, SHORT, BRICK>(mp.common, (const FramePose *)frames, mp.n_frames, wg_x, wg_y, wg_z,
                                                          mp.labels, free_frames, skip_frames);
+}
+
+// Ahead of a BRICK launch: which frames may do something to each super-brick -- the box of a workgroup's four bricks over
+// kSuperZ consecutive slice groups -- one WAVEFRONT per super-brick, one frame per lane (paired half-waves, as in the
+// launch's own prologue; the same classify_patch, so the same exactness argument, on a larger box).  Most of a realistic
+// launch's workgroups are skipped by every frame (the volume behind the surfaces and outside the views: 45 % of S-surf's
+// workgroups, more on a trajectory); with their word 0 they cost a dispatch instead of staging + barrier + four
+// classifications.  grid = ceil(super-bricks / 4) x 256 threads.
+__global__ __launch_bounds__(256) void classify_superbricks(MultiParamsInline mp, unsigned int *out, int n_wgx)
+{
+    typedef const char __attribute__((address_space(4))) *kernarg_ptr;
+    kernarg_ptr base = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    const FramePose *frames = (const FramePose *)(base + offsetof(MultiParamsInline, frames));
+    const IntegrateParams &p = mp.common;
+    const int id = (int)blockIdx.x * 4 + (int)threadIdx.y, lane = threadIdx.x;
+    if (id >= n_wgx * mp.nz_super) return;
+    const int wx = id / mp.nz_super, zs = id - wx * mp.nz_super;
+    const int total = p.brick_groups * p.bricks_per_group;
+    const int b0 = wx * 4, b3 = min(b0 + 3, total - 1);
+    if (b0 >= total) {
+        if (lane == 0) out[id] = 0u;
+        return;
+    }
+    const int g0 = b0 / p.bricks_per_group, i0 = b0 - g0 * p.bricks_per_group;
+    const int g3 = b3 / p.bricks_per_group, i3 = b3 - g3 * p.bricks_per_group;
+    // the four bricks lie side by side in one row group, or wrap into the next one (then: the full width of both)
+    const int xa = g0 == g3 ? i0 * p.brick_q * 4 : 0, xb = g0 == g3 ? (i3 + 1) * p.brick_q * 4 - 1 : p.dim_x - 1;
+    const int ya = g0 * p.brick_r, yb = min((g3 + 1) * p.brick_r - 1, p.dim_y - 1);
+    const int nz_groups = (p.nz + p.brick_s - 1) / p.brick_s;
+    const int zg0 = zs * kSuperZ, zg1 = min(zg0 + kSuperZ - 1, nz_groups - 1);
+    const int z0 = zg0 * p.brick_s, z1 = min((zg1 + 1) * p.brick_s - 1, p.nz - 1);
+    const int cls = classify_patch<true>(p, frames + (lane & 31), xa, xb, ya, yb, p.z_begin + z0, p.z_begin + z1);
+    const unsigned long long work = __ballot(cls != 2 && lane < mp.n_frames);
+    if (lane == 0) out[id] = (unsigned int)work;
 }
 
 // Experiment (variant 5): XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs, so

@@ -1,3 +1,5 @@
-for args in "--n 8 --edge 128" "--n 64 --edge 100" "--n 64 --edge 64" "--n 16 --edge 64" "--n 4 --edge 100"; do
-  python tools/batch_time.py $args --frames 320 2>&1 | grep -v amdgpu | grep -v "1024-voxel\|forced on"
+# super-brick pre-pass: variant 8 (bricks forced, with it) against 12 (without)
+one() { python bench.py "$@" --no-extras --no-traffic --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'])"; }
+for w in "ssurf" "traj" "ssurf --grid 200 --voxel-mm 4" "ssurf --grid 384" "traj --grid 512" "sfull --mode fused"; do
+  echo "$w: with $(one --workload $w --variant 8)   without $(one --workload $w --variant 12)"
 done
