@@ -260,9 +260,12 @@ tsdfk::IntegrateParams make_params(const tsdf_volume *v, const float *depth_dev,
     // brick view (tsdf_multiframe.hip.h, BRICK): the volume's wavefront brick, chosen at creation (choose_brick)
     p.brick_q = v->brick_q; p.brick_r = v->brick_r; p.brick_s = v->brick_s > 0 ? v->brick_s : 1;
     p.bricks_per_group = 0; p.brick_groups = 0;
+    p.brick_q_magic = 0; p.brick_per_magic = 0;
     if (p.brick_q > 0) {
         p.bricks_per_group = p.quads_per_row / p.brick_q;
         p.brick_groups = (c.dim_y + p.brick_r - 1) / p.brick_r;
+        p.brick_q_magic = 65536 / p.brick_q + 1;
+        p.brick_per_magic = 65536 / (p.brick_q * p.brick_r) + 1;
     }
     // The shared-reciprocal projection (tsdf_kernels.hip.h, fast_div2) is exact when no operand
     // needs div_scale's pre-scaling: bound every camera-frame coordinate of the slab by

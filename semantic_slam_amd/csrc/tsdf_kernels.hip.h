@@ -59,6 +59,7 @@ struct IntegrateParams {
     // consecutive ones, and the launch's z index counts slice groups.  brick_q = 0: no brick view (dim_x % 4 != 0).
     // The shape is the host's choice per volume (tsdf_capi.hip, choose_brick; tsdf_set_brick_shape).
     int brick_q, brick_r, brick_s, bricks_per_group, brick_groups;
+    int brick_q_magic, brick_per_magic;   // floor(2^16 / d) + 1 for d = brick_q and d = brick_q * brick_r: x / d for x < 64
     // host-proved magnitude bounds that make the shared-reciprocal projection exact (see fast_div2)
     int fast_ok;
     // 2^-20 <= trunc <= 2^20 and max_depth <= 2^59: diff / trunc may go through the shared refined reciprocal

@@ -418,11 +418,13 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
         return (size_t)lzz * p.chunks_per_slice + (size_t)((gy * p.quads_per_row + quad) >> 6);
     };
     if constexpr (BRICK) {
-        const int brick = b0 * 4 + (int)threadIdx.y;
+        const int brick = b0 * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.y);
         const int g = brick / p.bricks_per_group, i = brick - g * p.bricks_per_group;
+        // lane -> (slice, row, quad) of the brick: two divisions of a number below 64 by a divisor of at most 64, exact
+        // as (x * ceil(2^16 / d)) >> 16 (the host's brick_per_magic / brick_q_magic)
         const int per = p.brick_q * p.brick_r;
-        const int zz = (int)threadIdx.x / per, rem = (int)threadIdx.x - zz * per;
-        const int rr = rem / p.brick_q, qq = rem - rr * p.brick_q;
+        const int zz = (int)(((unsigned)threadIdx.x * (unsigned)p.brick_per_magic) >> 16), rem = (int)threadIdx.x - zz * per;
+        const int rr = (int)(((unsigned)rem * (unsigned)p.brick_q_magic) >> 16), qq = rem - rr * p.brick_q;
         xg = i * p.brick_q + qq;
         gy0 = g * p.brick_r + rr;
         lzz = lz * p.brick_s + zz;
@@ -878,7 +880,7 @@ __global__ __launch_bounds__(256, R == 2 ? 6 : (BRICK ? (LABELS ? 6 : TSDF_BRICK
         }
         __syncthreads();
         if constexpr (BRICK) {
-            const int brick = wg_x * 4 + (int)threadIdx.y;
+            const int brick = wg_x * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.y);
             const int g = brick / p.bricks_per_group, i = brick - g * p.bricks_per_group;
             const int xa = i * p.brick_q * 4, ya = g * p.brick_r;
             const int z0 = wg_z * p.brick_s, z1 = min(z0 + p.brick_s - 1, p.nz - 1);
@@ -924,7 +926,7 @@ __global__ __launch_bounds__(256) void classify_superbricks(MultiParamsInline mp
     kernarg_ptr base = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
     const FramePose *frames = (const FramePose *)(base + offsetof(MultiParamsInline, frames));
     const IntegrateParams &p = mp.common;
-    const int id = (int)blockIdx.x * 4 + (int)threadIdx.y, lane = threadIdx.x;
+    const int id = (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.y), lane = threadIdx.x;
     if (id >= n_wgx * mp.nz_super) return;
     const int wx = id / mp.nz_super, zs = id - wx * mp.nz_super;
     const int total = p.brick_groups * p.bricks_per_group;

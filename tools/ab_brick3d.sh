@@ -1,5 +1,4 @@
-# super-brick pre-pass: variant 8 (bricks forced, with it) against 12 (without)
 one() { python bench.py "$@" --no-extras --no-traffic --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'])"; }
-for w in "ssurf" "traj" "ssurf --grid 200 --voxel-mm 4" "ssurf --grid 384" "traj --grid 512" "sfull --mode fused"; do
-  echo "$w: with $(one --workload $w --variant 8)   without $(one --workload $w --variant 12)"
+for w in "ssurf" "traj" "ssurf --grid 200 --voxel-mm 4" "ssurf --grid 384" "sfull --mode fused"; do
+  echo "$w: $(one --workload $w)"
 done
