@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--no-traffic", action="store_true",
                     help="do not measure roofline.traffic (two short rocprofv3 --pmc child runs of this script)")
     ap.add_argument("--no-extract", action="store_true", help="N > 1: skip the halo exchange + extraction after the timed region")
+    ap.add_argument("--noise-mm", type=float, default=0.0, help="ssurf / traj: zero-mean Gaussian depth noise, sigma in mm (SURVEY.md 8d), rng seed 1234")
+    ap.add_argument("--holes", type=float, default=0.0, help="ssurf / traj: fraction of the image lost to invalid (zero) 8 x 8 pixel blocks, like a real sensor's dropouts")
     ap.add_argument("--voxel-mm", type=float, default=0.0, help="voxel size in mm (default: 5 at 512, 2 at 1024, else 2560 / grid)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
@@ -84,7 +86,7 @@ def parse():
 class Workload:
     """origin, truncation margin, base pose, the cam2world stream and the depth frame(s) it comes with."""
 
-    def __init__(self, name, dims, vs):
+    def __init__(self, name, dims, vs, noise_mm=0.0, holes=0.0):
         from semantic_slam_amd import synth
         self.name, self.dims, self.vs = name, dims, vs
         self.trunc = None            # None = the reference's 5 x voxel
@@ -121,6 +123,22 @@ class Workload:
             self.depths = [scene.depth(capi.multiply_matrix(binv, p), quantize=True) for p in self.poses]
             self.desc = (f"the {len(self.poses)} keyframe poses of the reference's saved fr3_office run (result/rgbd/bundle.txt), "
                          "base = first keyframe, sphere + wall depth re-rendered per pose, quantised at 1/5000 m")
+        if name in ("ssurf", "traj") and (noise_mm > 0 or holes > 0):
+            # a sensor's imperfections (Gaussian noise, sigma 2 mm; dropouts as zero blocks), then the
+            # 1/5000 m quantisation again
+            rng = np.random.default_rng(1234)
+            out = []
+            for d in self.depths:
+                d = d.copy()
+                if noise_mm > 0:
+                    d = np.where(d > 0, d + rng.normal(0.0, noise_mm * 1e-3, d.shape).astype(np.float32), d)
+                    d = (np.round(d * 5000.0) / 5000.0).astype(np.float32)
+                if holes > 0:
+                    drop = rng.uniform(0, 1, (d.shape[0] // 8, d.shape[1] // 8)) < holes
+                    d[np.kron(drop, np.ones((8, 8), bool))] = 0.0
+                out.append(np.ascontiguousarray(d, np.float32))
+            self.depths = out
+            self.desc += f"; Gaussian noise sigma {noise_mm:g} mm, {holes * 100:g} % of the image dropped in 8 x 8 blocks"
         self.n_pose = len(self.poses)
 
     def block(self, start, n):
@@ -293,7 +311,7 @@ def main():
     comm_dev = "cpu" if backend == "gloo" else "cuda"
 
     dims, vs, part_world = grid_for(args, world)
-    W = Workload(args.workload, dims, vs)
+    W = Workload(args.workload, dims, vs, args.noise_mm, args.holes)
     D = args.grid
 
     # z-slab of this rank (ref layout is z-major, so a slab is one contiguous range)
@@ -536,26 +554,30 @@ def main():
     if extras and args.workload in ("sband", "sfull"):
         # The realistic workload of SURVEY.md section 8(d): sphere + wall, orbit of 64 poses, depth re-rendered per pose
         # (64 frames resident in HBM), through the sequence path.
-        Ws = Workload("ssurf", dims, vs)
-        with capi.Volume(capi.make_config(dims, vs, Ws.origin, device=local_rank)) as sv_:
-            s_dev = [torch.from_numpy(d).cuda() for d in Ws.depths]
-            def sblock(start, n):
-                poses, idx = Ws.block(start, n)
-                return sv_.integrate_frames_timed([s_dev[i].data_ptr() for i in idx], poses)
-            sblock(0, 64)
-            tot, steps = 0.0, 0
-            while tot < 150.0:
-                tot += sblock(64 + steps, 64)
-                steps += 64
-            _, w_r = sv_.download()
-            upd_r = float(w_r.astype(np.float64).sum()) / (64 + steps)
-            del w_r, s_dev
-        ms_r = tot / steps
-        line["realistic_workload"] = {
-            "workload": f"ssurf {dims[0]}x{dims[1]}x{dims[2]} @ {vs * 1000:g} mm: {Ws.desc}; fused sequence path",
-            "ms_per_step": round(ms_r, 5), "value": round(n_global / ms_r / 1e3, 1), "unit": "Mvoxels/s",
-            "updated_fraction": round(upd_r / n_global, 4), "frames": steps,
-            "algorithmic_GBps_at_16B_per_update": round((16.0 * upd_r + frame_bytes) / (ms_r * 1e-3) / 1e9, 1)}
+        def realistic(noise_mm, holes, budget_ms):
+            Ws = Workload("ssurf", dims, vs, noise_mm, holes)
+            with capi.Volume(capi.make_config(dims, vs, Ws.origin, device=local_rank)) as sv_:
+                s_dev = [torch.from_numpy(d).cuda() for d in Ws.depths]
+                def sblock(start, n):
+                    poses, idx = Ws.block(start, n)
+                    return sv_.integrate_frames_timed([s_dev[i].data_ptr() for i in idx], poses)
+                sblock(0, 64)
+                tot, steps = 0.0, 0
+                while tot < budget_ms:
+                    tot += sblock(64 + steps, 64)
+                    steps += 64
+                _, w_r = sv_.download()
+                upd_r = float(w_r.astype(np.float64).sum()) / (64 + steps)
+                del w_r, s_dev
+            ms_r = tot / steps
+            return {"workload": f"ssurf {dims[0]}x{dims[1]}x{dims[2]} @ {vs * 1000:g} mm: {Ws.desc}; fused sequence path",
+                    "ms_per_step": round(ms_r, 5), "value": round(n_global / ms_r / 1e3, 1), "unit": "Mvoxels/s",
+                    "updated_fraction": round(upd_r / n_global, 4), "frames": steps,
+                    "algorithmic_GBps_at_16B_per_update": round((16.0 * upd_r + frame_bytes) / (ms_r * 1e-3) / 1e9, 1)}
+        line["realistic_workload"] = realistic(0.0, 0.0, 150.0)
+        # the same scene through a sensor's imperfections: Gaussian noise (sigma 2 mm) and 5 % of every frame
+        # dropped in 8 x 8 pixel blocks -- free-space bricks behind a dropout cannot be claimed as a whole any more
+        line["realistic_workload_noisy"] = realistic(2.0, 0.05, 60.0)
     if extras and len(W.depths) == 1:
         # PCIe-inclusive rate of the reference-style call (tsdf_integrate: host depth pointer -> pinned staging -> H2D on a
         # copy stream).  By default the library collects such frames and applies them 32 at a time as one fused sequence
