@@ -455,8 +455,10 @@ int launch_masked_bricks(tsdf_volume *v, tsdfk::IntegrateParams &p)
 //   7        as 0 but never with the per-workgroup patch classification (the per-voxel kernel alone)
 //   8        as 0 but always with it (0 decides per launch from the previous launch's claims)
 //   9        as 0 with the workgroups of a fused launch dispatched in memory order instead of slices-fastest (A/B)
+//   10       as 0 with slices fastest but without the rotation that spreads a slice group over the XCDs (A/B)
 //   11       as 8 (always classified) with round 1's shape: 256 x 1 rows per wavefront, classified per workgroup (A/B
-//            of the brick mapping: 64 x 4 voxels per wavefront, classified per wavefront, the default when classifying)
+//            of the brick mapping: q x r x s voxels per wavefront, classified per wavefront, the default when classifying)
+//   12       as 8 without the super-brick pre-pass (A/B)
 //   1        scalar kernel integrate_rows<1> (any dim_x)
 //   2        first version integrate_rows<4> (one row per wavefront, no elision)
 //   16 + c   experiments: c = (rsel << 2) | (elide << 1) | nt, R = 1, 2, 4 for rsel = 0, 1, 2
