@@ -172,3 +172,48 @@ def test_instance_masked_object_volumes_skip_exactly(cuda, oracle, classified, d
             t, w = vol.download()
         assert np.array_equal(w, rw) and np.array_equal(t.view(np.uint32), rt.view(np.uint32)), f"volume {cfg.id}"
     assert sum(float(rw.sum()) for _, rw in refs) > 10000 and sum(1 for _, rw in refs if rw.sum() > 1000) >= 2
+
+
+def test_deferred_batch_keeps_call_order_with_borrowed_handles(cuda, oracle):
+    """Frames given to the batch and frames given to a member through its borrowed handle are applied in call order:
+    batch frame A (collected), member frame B (the batch's collected frames are applied first), batch frame C, an
+    observation of ONE member (flushes the whole batch), batch frame D, destruction with D still collected (dropped
+    without a crash; nothing can tell whether it was applied)."""
+    dims, vs = (200, 200, 200), 0.004       # 8 M voxels each: the deferred route
+    origins = [np.array([-0.4, -0.4, 0.7], np.float32), np.array([-0.3, -0.45, 0.9], np.float32)]
+    cfgs = [capi.make_config(dims, vs, o, vol_id=i) for i, o in enumerate(origins)]
+    scene = synth.SurfScene(dims, vs, origins[0])
+    masks = []
+    for r in ((100, 400, 150, 500), (60, 300, 250, 620)):
+        m = np.zeros((480, 640), np.uint8)
+        m[r[0]:r[1], r[2]:r[3]] = 255
+        masks.append(m)
+    poses = [scene.pose(k, 6) for k in range(4)]
+    depths = [scene.depth(p, quantize=True) for p in poses]
+    refs = [oracle.init_grid(dims) for _ in cfgs]
+
+    def ref_integrate(i, k, masked=True):
+        d = oracle.mask_depth(depths[k], masks[i]) if masked else depths[k]
+        oracle.integrate(cfgs[i].cam_K, poses[k], d, dims, origins[i], vs, cfgs[i].trunc_margin, refs[i][0], refs[i][1], threads=8)
+
+    d_dev = [cuda.from_numpy(d).cuda() for d in depths]
+    m_dev = [cuda.from_numpy(m).cuda() for m in masks]
+    batch = capi.Batch(cfgs)
+    try:
+        mp = [m.data_ptr() for m in m_dev]
+        batch.integrate_device(d_dev[0].data_ptr(), mp, poses[0])               # A
+        for i in range(2):
+            ref_integrate(i, 0)
+        batch.volumes[1].integrate_device(d_dev[1].data_ptr(), poses[1])        # B: member 1 only, unmasked
+        ref_integrate(1, 1, masked=False)
+        batch.integrate_device(d_dev[2].data_ptr(), mp, poses[2])               # C
+        for i in range(2):
+            ref_integrate(i, 2)
+        t1, w1 = batch.volumes[1].download()                                    # observes member 1: everything so far applies
+        assert np.array_equal(w1, refs[1][1]) and np.array_equal(t1.view(np.uint32), refs[1][0].view(np.uint32))
+        t0, w0 = batch.volumes[0].download()
+        assert np.array_equal(w0, refs[0][1]) and np.array_equal(t0.view(np.uint32), refs[0][0].view(np.uint32))
+        assert refs[1][1].max() >= 3 and refs[0][1].max() >= 2
+        batch.integrate_device(d_dev[3].data_ptr(), mp, poses[3])               # D: still collected when the batch goes
+    finally:
+        batch.close()
