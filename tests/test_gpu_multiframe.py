@@ -136,7 +136,7 @@ def test_classification_is_dropped_when_it_claims_nothing_and_probed_again(cuda,
     ref_t, ref_w = oracle.init_grid(dims)
     d_holes, d_clean = cuda.from_numpy(holes).cuda(), cuda.from_numpy(clean).cuda()
     with capi.Volume(cfg) as vol:
-        vol.set_kernel_variant(0)      # the default policy is what is tested, whatever TSDF_DEFAULT_VARIANT says
+        vol.set_kernel_variant(0)      # the default policy is what is tested
         fpl = vol.frames_per_launch
         seen = []
         for launch in range(12):
