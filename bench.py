@@ -561,13 +561,13 @@ def main():
                 def sblock(start, n):
                     poses, idx = Ws.block(start, n)
                     return sv_.integrate_frames_timed([s_dev[i].data_ptr() for i in idx], poses)
-                sblock(0, 64)
+                sblock(0, 192)          # tables and pre-pass buffers allocated, the per-launch decision settled, clocks up
                 tot, steps = 0.0, 0
-                while tot < budget_ms:
-                    tot += sblock(64 + steps, 64)
-                    steps += 64
+                while tot < budget_ms:  # 256 steps (8 launches) per call, as the headline loop queues them
+                    tot += sblock(192 + steps, 256)
+                    steps += 256
                 _, w_r = sv_.download()
-                upd_r = float(w_r.astype(np.float64).sum()) / (64 + steps)
+                upd_r = float(w_r.astype(np.float64).sum()) / (192 + steps)
                 del w_r, s_dev
             ms_r = tot / steps
             return {"workload": f"ssurf {dims[0]}x{dims[1]}x{dims[2]} @ {vs * 1000:g} mm: {Ws.desc}; fused sequence path",
