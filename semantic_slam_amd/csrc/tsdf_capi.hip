@@ -366,7 +366,7 @@ bool classify_one_frame(const tsdf_volume *v, int64_t launch_voxels)
 // Depth tile tables (summary + sparse table, tsdf_multiframe.hip.h) of n images depth[i] x mask[i] into tables[i], queued
 // on `stream`; two small launches per 32 images.
 int build_tile_tables(hipStream_t stream, const tsdf_config &c, const tsdfk::IntegrateParams &p, const float *const *depth,
-                      const uint8_t *const *masks, int n, float2 *tables)
+                      const uint8_t *const *masks, int n, float2 *tables, unsigned long long *zero_me = nullptr)
 {
     const size_t per = tile_table_elems_host(p.tiles_w, p.tiles_h);
     for (int k = 0; k < n; k += tsdfk::kMaxFramesPerLaunch) {
@@ -379,9 +379,20 @@ int build_tile_tables(hipStream_t stream, const tsdf_config &c, const tsdfk::Int
         tp.tiles = tables + (size_t)k * per;
         tp.H = c.im_height; tp.W = c.im_width; tp.tiles_w = p.tiles_w; tp.tiles_h = p.tiles_h;
         tp.max_depth = c.max_depth;
-        hipLaunchKernelGGL(tsdfk::depth_tile_summary, dim3((unsigned)((p.tiles_w * p.tiles_h + 3) / 4), m), dim3(64, 4), 0, stream, tp);
-        hipLaunchKernelGGL(tsdfk::tile_sparse_table, dim3((unsigned)tile_levels_host(p.tiles_w), m), dim3(256), 0, stream, tp.tiles,
-                           p.tiles_w, p.tiles_h);
+        if (tsdfk::kTile == 16) {   // whole-row reads: one wavefront per strip of four tiles
+            const int strips = ((p.tiles_w + 3) / 4) * p.tiles_h;
+            hipLaunchKernelGGL(tsdfk::depth_tile_summary, dim3((unsigned)((strips + 3) / 4), m), dim3(64, 4), 0, stream, tp);
+        } else {
+            hipLaunchKernelGGL(tsdfk::depth_tile_summary_per_tile, dim3((unsigned)((p.tiles_w * p.tiles_h + 3) / 4), m), dim3(64, 4), 0, stream, tp);
+        }
+        if (p.tiles_w * p.tiles_h <= tsdfk::kTileLdsEntries) {
+            hipLaunchKernelGGL(tsdfk::tile_sparse_table, dim3((unsigned)tile_levels_host(p.tiles_w), m), dim3(256), 0, stream, tp.tiles,
+                               p.tiles_w, p.tiles_h, k == 0 ? zero_me : (unsigned long long *)nullptr);
+        } else {
+            if (zero_me && k == 0) HIP_TRY(hipMemsetAsync(zero_me, 0, sizeof(unsigned long long), stream));
+            hipLaunchKernelGGL(tsdfk::tile_sparse_table_scan, dim3((unsigned)tile_levels_host(p.tiles_w), m), dim3(256), 0, stream, tp.tiles,
+                               p.tiles_w, p.tiles_h);
+        }
     }
     HIP_TRY(hipGetLastError());
     return TSDF_OK;
@@ -707,14 +718,13 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
                     HIP_TRY(hipHostMalloc((void **)&v->h_claims, sizeof(unsigned long long), hipHostMallocDefault));
                     HIP_TRY(hipEventCreateWithFlags(&v->claims_done, hipEventDisableTiming));
                 }
-                HIP_TRY(hipMemsetAsync(v->d_claims, 0, sizeof(unsigned long long), v->stream));
-                mi.common.claim_counter = v->d_claims;
+                mi.common.claim_counter = v->d_claims;   // cleared by the table kernel below (classify is true here)
             }
             if (classify) {
                 // depth tile tables of the n frames (two small launches), then the kernel that consults them
                 const size_t per_frame = tile_table_elems_host(mi.common.tiles_w, mi.common.tiles_h);
                 if (!v->d_tiles) HIP_TRY(hipMalloc((void **)&v->d_tiles, tsdfk::kMaxFramesPerLaunch * per_frame * sizeof(float2)));
-                int rc = build_tile_tables(v->stream, c, mi.common, depth_dev, masks_dev, n, v->d_tiles);
+                int rc = build_tile_tables(v->stream, c, mi.common, depth_dev, masks_dev, n, v->d_tiles, count_claims ? v->d_claims : nullptr);
                 if (rc) return rc;
                 for (int f = 0; f < n; ++f) mi.frames[f].tiles = v->d_tiles + (size_t)f * per_frame;
                 for (int f = n; f < tsdfk::kMaxFramesPerLaunch; ++f) mi.frames[f] = mi.frames[0];

@@ -65,7 +65,7 @@ __device__ __forceinline__ int tile_levels(int n) { return 32 - __clz(n); }   //
 __device__ __forceinline__ size_t tile_table_elems(int tw, int th) { return (size_t)tile_levels(tw) * tile_levels(th) * tw * th; }
 
 // block = 64 x 4: one wavefront per tile, four tiles per workgroup; grid = (ceil(tiles / 4), frames)
-__global__ __launch_bounds__(256) void depth_tile_summary(TileSummaryParams tp)
+__global__ __launch_bounds__(256) void depth_tile_summary_per_tile(TileSummaryParams tp)
 {
     const int tile = blockIdx.x * 4 + threadIdx.y, f = blockIdx.y;
     if (tile >= tp.tiles_w * tp.tiles_h) return;
@@ -106,6 +106,80 @@ __global__ __launch_bounds__(256) void depth_tile_summary(TileSummaryParams tp)
     }
 }
 
+// The same values from whole-row reads: one wavefront per STRIP of four horizontally adjacent 16 x 16 tiles (16 rows x 64
+// pixels): a load instruction covers four rows of 256 contiguous bytes (16 lanes x 16 B per row) instead of sixteen 64-byte
+// row pieces, a lane accumulates its 4 rows x 4 pixels -- all in one tile -- and the 16 lanes of a tile combine by four
+// shuffles; min / max are exact and order-free, so the table is the one depth_tile_summary_per_tile builds (the claim
+// statistics of S-surf are identical).  The two table kernels were 72 us of a 32-frame launch -- a quarter of a 200^3 one.
+// block = 64 x 4 (four strips per workgroup); grid = (ceil(strips / 4), frames).
+__global__ __launch_bounds__(256) void depth_tile_summary(TileSummaryParams tp)
+{
+    // (written for kTile == 16: the host launches depth_tile_summary_per_tile for any other tile size)
+    const int strips_w = (tp.tiles_w + 3) / 4;
+    const int strip = blockIdx.x * 4 + threadIdx.y, f = blockIdx.y;
+    if (strip >= strips_w * tp.tiles_h) return;
+    const int ty = strip / strips_w, sx = strip - ty * strips_w;
+    const int lane = threadIdx.x, c4 = lane & 15, rr = lane >> 4;
+    const int px0 = sx * 64 + c4 * 4;
+    const float *d = tp.depth[f];
+    const uint8_t *m = tp.mask[f];
+    const float inf = __builtin_inff();
+    float mn = inf, mx = -inf;
+    bool all_valid = true, nan = false;
+    const bool vec = (tp.W & 3) == 0 && (reinterpret_cast<uintptr_t>(d) & 15) == 0 &&
+                     (m == nullptr || (reinterpret_cast<uintptr_t>(m) & 3) == 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int py = ty * kTile + rr + 4 * i;
+        if (py >= tp.H || px0 >= tp.W) continue;
+        float v[4];
+        bool in[4];
+        const size_t at = (size_t)py * tp.W + px0;
+        if (vec) {      // W % 4 == 0: the four pixels are inside the row together
+            const float4 q = *reinterpret_cast<const float4 *>(d + at);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+            in[0] = in[1] = in[2] = in[3] = true;
+            if (m != nullptr) {
+                const uchar4 k = *reinterpret_cast<const uchar4 *>(m + at);
+                v[0] = v[0] * (k.x >= 128 ? 1.0f : 0.0f); v[1] = v[1] * (k.y >= 128 ? 1.0f : 0.0f);   // inf * 0 = NaN, as in the kernel
+                v[2] = v[2] * (k.z >= 128 ? 1.0f : 0.0f); v[3] = v[3] * (k.w >= 128 ? 1.0f : 0.0f);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                in[j] = px0 + j < tp.W;
+                v[j] = in[j] ? d[at + j] : 0.0f;
+                if (in[j] && m != nullptr) v[j] = v[j] * (m[at + j] >= 128 ? 1.0f : 0.0f);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (!in[j]) continue;
+            nan |= v[j] != v[j];
+            const bool valid = (v[j] > 0.0f) & (v[j] <= tp.max_depth);
+            all_valid &= valid;
+            if (valid) { mn = fminf(mn, v[j]); mx = fmaxf(mx, v[j]); }
+        }
+    }
+    // the 16 lanes of a tile: c4 in [4k, 4k + 3] (lane bits 0, 1) x the four row groups (lane bits 4, 5)
+    mn = fminf(mn, __shfl_xor(mn, 1));  mx = fmaxf(mx, __shfl_xor(mx, 1));
+    mn = fminf(mn, __shfl_xor(mn, 2));  mx = fmaxf(mx, __shfl_xor(mx, 2));
+    mn = fminf(mn, __shfl_xor(mn, 16)); mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mn = fminf(mn, __shfl_xor(mn, 32)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const unsigned long long bad = __ballot(!all_valid), nans = __ballot(nan);
+    if ((lane & 3) == 0 && rr == 0) {
+        const int k = c4 >> 2, tx = sx * 4 + k;
+        if (tx < tp.tiles_w) {
+            const unsigned long long tile_lanes = 0x000F000F000F000Full << (4 * k);
+            const bool every_valid = (bad & tile_lanes) == 0ull, any_nan = (nans & tile_lanes) != 0ull;
+            float2 out;
+            out.x = (every_valid && !any_nan) ? mn : -inf;
+            out.y = any_nan ? inf : mx;
+            tp.tiles[(size_t)f * tile_table_elems(tp.tiles_w, tp.tiles_h) + (size_t)ty * tp.tiles_w + tx] = out;
+        }
+    }
+}
+
 // The upper levels from level (0, 0), one workgroup per (x level j, frame): first level (0, j) straight from the base
 // tiles -- the combination over tiles tx .. min(tx + 2^j - 1, tw - 1) of each row (min and max are exact and
 // idempotent, so any evaluation order gives the same bits) -- kept in LDS, then, after ONE barrier, the levels (i, j)
@@ -114,7 +188,7 @@ __global__ __launch_bounds__(256) void depth_tile_summary(TileSummaryParams tp)
 // kTileLdsEntries tiles fall back to reading level (0, j) from memory after the barrier (same values).
 constexpr int kTileLdsEntries = kTile == 8 ? 5120 : 2048;   // float2: 2 x 40 KiB of LDS (a 640 x 480 frame has 4800 8-pixel tiles)
 
-__global__ __launch_bounds__(256) void tile_sparse_table(float2 *tables, int tw, int th)
+__global__ __launch_bounds__(256) void tile_sparse_table_scan(float2 *tables, int tw, int th)
 {
     const int lj = tile_levels(tw), li = tile_levels(th), n = tw * th;
     const int j = blockIdx.x;                      // this workgroup's x level
@@ -156,6 +230,50 @@ __global__ __launch_bounds__(256) void tile_sparse_table(float2 *tables, int tw,
             }
             dst[k] = acc;
         }
+    }
+}
+
+// The same table by doubling, for frames whose tiles fit LDS (n <= kTileLdsEntries; 640 x 480: 1200): a level is the
+// combination of two entries of the level below -- (0, s + 1) at tx from (0, s) at tx and at min(tx + 2^s, tw - 1), (i + 1, j)
+// from (i, j) at ty and at min(ty + 2^i, th - 1); the clamped partner lies inside the clipped range, and min / max are
+// idempotent, so every entry is the exact combination over its clipped block, as the scan version computes it.  One
+// workgroup per (x level j, frame): j + levels_y - 1 steps of two LDS reads per entry with a barrier each, instead of
+// 2^j + 2^i reads per entry.  zero_me (may be null): a word this launch clears for the kernel that follows it on the
+// stream (the fused launch's claim counter: saves a memset dispatch per launch).
+__global__ __launch_bounds__(256) void tile_sparse_table(float2 *tables, int tw, int th, unsigned long long *zero_me)
+{
+    if (zero_me != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *zero_me = 0ull;
+    const int lj = tile_levels(tw), li = tile_levels(th), n = tw * th;
+    const int j = blockIdx.x;
+    float2 *T = tables + (size_t)blockIdx.y * tile_table_elems(tw, th);
+    __shared__ float2 buf[2][kTileLdsEntries];
+    float2 *cur = buf[0], *nxt = buf[1];
+    for (int k = threadIdx.x; k < n; k += blockDim.x) cur[k] = T[k];
+    __syncthreads();
+    for (int s = 0; s < j; ++s) {              // row levels (0, 1) .. (0, j)
+        const int step = 1 << s;
+        for (int k = threadIdx.x; k < n; k += blockDim.x) {
+            const int ty = k / tw, tx = k - ty * tw;
+            const float2 a = cur[k], b = cur[ty * tw + min(tx + step, tw - 1)];
+            nxt[k] = make_float2(fminf(a.x, b.x), fmaxf(a.y, b.y));
+        }
+        __syncthreads();
+        float2 *t = cur; cur = nxt; nxt = t;
+    }
+    if (j > 0)
+        for (int k = threadIdx.x; k < n; k += blockDim.x) T[(size_t)j * n + k] = cur[k];     // level (0, j); (0, 0) is the input
+    for (int i = 1; i < li; ++i) {             // column levels (1, j) .. (li - 1, j)
+        const int step = 1 << (i - 1);
+        float2 *dst = T + (size_t)(i * lj + j) * n;
+        for (int k = threadIdx.x; k < n; k += blockDim.x) {
+            const int ty = k / tw;
+            const float2 a = cur[k], b = cur[k + (min(ty + step, th - 1) - ty) * tw];
+            const float2 c = make_float2(fminf(a.x, b.x), fmaxf(a.y, b.y));
+            nxt[k] = c;
+            dst[k] = c;
+        }
+        __syncthreads();
+        float2 *t = cur; cur = nxt; nxt = t;
     }
 }
 
