@@ -183,3 +183,45 @@ def test_large_image_tile_table_beyond_lds(cuda, oracle):
                 assert free > 0 and skipped > 0
             t, wgt = vol.download()
         assert np.array_equal(wgt, ref_w) and np.array_equal(t.view(np.uint32), ref_t.view(np.uint32)), variant
+
+
+def test_unaligned_frame_buffers(cuda, oracle):
+    """Depth frames and masks at addresses that are not multiples of 16 / 4 bytes (views into larger buffers): the tile
+    summary's whole-row reads need aligned rows and must fall back to element reads -- same tables, same claims, same bits."""
+    dims, vs = (256, 64, 32), 0.002
+    origin = synth.surf_volume(256, vs, 0.7)
+    cfg = capi.make_config(dims, vs, origin)
+    scene = synth.SurfScene(dims, vs, origin)
+    near, far = float(origin[2]), float(origin[2] + dims[2] * vs)
+    frames = []
+    for k in range(5):
+        pose = scene.pose(k, 9)
+        depth = scene.depth(pose, quantize=True) if k % 2 else np.full((H, W), far + 0.3, np.float32)
+        mask = np.zeros((H, W), np.uint8)
+        if k % 2:
+            mask[225:275, 180 + 10 * k:460] = 255       # narrower than the volume's footprint: bricks outside it see nothing
+        else:
+            mask[40 + 10 * k:400, 60:600 - 20 * k] = 255
+        frames.append((pose, depth, mask))
+    ref_t, ref_w = oracle.init_grid(dims)
+    for pose, depth, mask in frames:
+        oracle.integrate(cfg.cam_K, pose, oracle.mask_depth(depth, mask), dims, origin, vs, cfg.trunc_margin, ref_t, ref_w, threads=8)
+    stats = {}
+    for d_off, m_off in ((0, 0), (1, 1), (3, 2)):      # elements: depth pointer % 16 = 0, 4, 12; mask pointer % 4 = 0, 1, 2
+        d_buf = [cuda.zeros(H * W + 8, dtype=cuda.float32, device="cuda") for _ in frames]
+        m_buf = [cuda.zeros(H * W + 8, dtype=cuda.uint8, device="cuda") for _ in frames]
+        for (_, depth, mask), db, mb in zip(frames, d_buf, m_buf):
+            db[d_off:d_off + H * W].copy_(cuda.from_numpy(depth.ravel()))
+            mb[m_off:m_off + H * W].copy_(cuda.from_numpy(mask.ravel()))
+        cuda.cuda.synchronize()
+        d_ptr = [db.data_ptr() + 4 * d_off for db in d_buf]
+        m_ptr = [mb.data_ptr() + m_off for mb in m_buf]
+        assert d_ptr[0] % 16 == (4 * d_off) % 16 and m_ptr[0] % 4 == m_off % 4
+        with capi.Volume(cfg) as vol:
+            vol.set_kernel_variant(8)
+            vol.shortcut_stats(True)
+            vol.integrate_frames_device(d_ptr, np.stack([p for p, _, _ in frames]), m_ptr)
+            stats[(d_off, m_off)] = vol.shortcut_stats(False)
+            t, w = vol.download()
+        assert np.array_equal(w, ref_w) and np.array_equal(t.view(np.uint32), ref_t.view(np.uint32)), (d_off, m_off)
+    assert stats[(1, 1)] == stats[(0, 0)] == stats[(3, 2)] and stats[(0, 0)][1] > 0 and stats[(0, 0)][2] > 0, stats
