@@ -326,6 +326,15 @@ int tsdf_selftest_fastdiv_band(int32_t device, uint64_t seed, uint64_t n_samples
  */
 int tsdf_selftest_round(int32_t device, uint64_t *mismatches, float first_bad[4]);
 
+/*
+ * Device self-test of the depth tile tables the classified launches consult: builds the table of one frame (depth x mask,
+ * mask_dev may be NULL) with the kernels the library launches (whole-row strips, levels by doubling) and with the plain
+ * ones (one wavefront per tile, levels by scanning) and counts the entries that differ in any bit; *mismatches must come
+ * back 0.
+ */
+int tsdf_selftest_tile_tables(int32_t device, const float *depth_dev, const uint8_t *mask_dev, int32_t im_height,
+                              int32_t im_width, float max_depth, uint64_t *mismatches);
+
 /* Select the Integrate kernel variant (0 = default; others are listed in DESIGN.md). */
 int tsdf_set_kernel_variant(tsdf_volume *vol, int32_t variant);
 

@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "tsdf_sync", "tsdf_download", "tsdf_copy_slices", "tsdf_upload", "tsdf_refresh_summary", "tsdf_device_ptrs", "tsdf_slab_voxels", "tsdf_frames_per_launch", "tsdf_shortcut_stats", "tsdf_classification_info",
     "tsdf_get_config", "tsdf_last_cam2base", "tsdf_set_stream", "tsdf_get_stream",
     "tsdf_count_surface", "tsdf_extract_surface", "tsdf_extract_crossings", "tsdf_extract_mesh", "tsdf_save_mesh_ply", "tsdf_save_mesh_welded_ply", "tsdf_save_ply", "tsdf_save_bin", "tsdf_load_bin", "tsdf_save_state", "tsdf_load_state",
-    "tsdf_integrate_sequence_timed", "tsdf_integrate_frames_timed", "tsdf_probe_graph_replay", "tsdf_probe_stream", "tsdf_selftest_fastdiv", "tsdf_selftest_fastdiv_band", "tsdf_selftest_round", "tsdf_set_kernel_variant", "tsdf_set_brick_shape", "tsdf_brick_shape", "tsdf_last_error",
+    "tsdf_integrate_sequence_timed", "tsdf_integrate_frames_timed", "tsdf_probe_graph_replay", "tsdf_probe_stream", "tsdf_selftest_fastdiv", "tsdf_selftest_fastdiv_band", "tsdf_selftest_round", "tsdf_selftest_tile_tables", "tsdf_set_kernel_variant", "tsdf_set_brick_shape", "tsdf_brick_shape", "tsdf_last_error",
     "tsdf_version", "tsdf_multiply_matrix", "tsdf_invert_matrix",
     "tsdf_labels_enable", "tsdf_compose_labels", "tsdf_integrate_labels_device", "tsdf_integrate_frames_labels_device",
     "tsdf_download_labels",
@@ -111,6 +111,7 @@ def load():
     L.tsdf_selftest_fastdiv.argtypes = [C.c_int32, C.c_uint64, C.c_uint64, C.c_float, C.c_float, C.POINTER(C.c_uint64), f32p]
     L.tsdf_selftest_fastdiv_band.argtypes = [C.c_int32, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), f32p]
     L.tsdf_selftest_round.argtypes = [C.c_int32, C.POINTER(C.c_uint64), f32p]
+    L.tsdf_selftest_tile_tables.argtypes = [C.c_int32, vp, vp, C.c_int32, C.c_int32, C.c_float, C.POINTER(C.c_uint64)]
     L.tsdf_set_kernel_variant.argtypes = [vp, C.c_int32]
     L.tsdf_set_brick_shape.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
     L.tsdf_brick_shape.argtypes = [vp, C.POINTER(C.c_int32)]
@@ -240,6 +241,14 @@ def selftest_round(device=0):
     bad = (C.c_float * 4)()
     check(load().tsdf_selftest_round(device, C.byref(cnt), bad), "tsdf_selftest_round")
     return cnt.value, list(bad)
+
+
+def selftest_tile_tables(depth_ptr, mask_ptr, im_height, im_width, max_depth=6.0, device=0):
+    """Entries of one frame's depth tile table that differ between the launched kernels and the plain ones (must be 0)."""
+    cnt = C.c_uint64()
+    check(load().tsdf_selftest_tile_tables(device, depth_ptr, mask_ptr, im_height, im_width, max_depth, C.byref(cnt)),
+          "tsdf_selftest_tile_tables")
+    return cnt.value
 
 
 class Volume:

@@ -1660,6 +1660,51 @@ int tsdf_selftest_round(int32_t device, uint64_t *mismatches, float first_bad[4]
     return TSDF_OK;
 }
 
+int tsdf_selftest_tile_tables(int32_t device, const float *depth_dev, const uint8_t *mask_dev, int32_t im_height,
+                              int32_t im_width, float max_depth, uint64_t *mismatches)
+{
+    if (!depth_dev || !mismatches || im_height <= 0 || im_width <= 0)
+        return fail(TSDF_ERR_INVALID, "tsdf_selftest_tile_tables: bad argument");
+    HIP_TRY(hipSetDevice(device));
+    const int tw = (im_width + tsdfk::kTile - 1) / tsdfk::kTile, th = (im_height + tsdfk::kTile - 1) / tsdfk::kTile;
+    const size_t per = tile_table_elems_host(tw, th);
+    float2 *d_a = nullptr, *d_b = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_a, per * sizeof(float2)));
+    if (hipMalloc((void **)&d_b, per * sizeof(float2)) != hipSuccess) { (void)hipFree(d_a); return fail(TSDF_ERR_HIP, "tsdf_selftest_tile_tables: hipMalloc"); }
+    (void)hipMemset(d_a, 0xff, per * sizeof(float2));
+    (void)hipMemset(d_b, 0x7f, per * sizeof(float2));
+    tsdfk::TileSummaryParams tp;
+    for (int f = 0; f < tsdfk::kMaxFramesPerLaunch; ++f) { tp.depth[f] = depth_dev; tp.mask[f] = mask_dev; }
+    tp.H = im_height; tp.W = im_width; tp.tiles_w = tw; tp.tiles_h = th; tp.max_depth = max_depth;
+    const unsigned lj = (unsigned)tile_levels_host(tw);
+    // a: the kernels the library launches (strips of four tiles, doubling in LDS when the frame's tiles fit)
+    tp.tiles = d_a;
+    if (tsdfk::kTile == 16)
+        hipLaunchKernelGGL(tsdfk::depth_tile_summary, dim3((unsigned)((((tw + 3) / 4) * th + 3) / 4), 1), dim3(64, 4), 0, 0, tp);
+    else
+        hipLaunchKernelGGL(tsdfk::depth_tile_summary_per_tile, dim3((unsigned)((tw * th + 3) / 4), 1), dim3(64, 4), 0, 0, tp);
+    if (tw * th <= tsdfk::kTileLdsEntries)
+        hipLaunchKernelGGL(tsdfk::tile_sparse_table, dim3(lj, 1), dim3(256), 0, 0, d_a, tw, th, (unsigned long long *)nullptr);
+    else
+        hipLaunchKernelGGL(tsdfk::tile_sparse_table_scan, dim3(lj, 1), dim3(256), 0, 0, d_a, tw, th);
+    // b: one wavefront per tile, levels by scanning
+    tp.tiles = d_b;
+    hipLaunchKernelGGL(tsdfk::depth_tile_summary_per_tile, dim3((unsigned)((tw * th + 3) / 4), 1), dim3(64, 4), 0, 0, tp);
+    hipLaunchKernelGGL(tsdfk::tile_sparse_table_scan, dim3(lj, 1), dim3(256), 0, 0, d_b, tw, th);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    std::vector<float2> a(per), b(per);
+    if (e == hipSuccess) e = hipMemcpy(a.data(), d_a, per * sizeof(float2), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(b.data(), d_b, per * sizeof(float2), hipMemcpyDeviceToHost);
+    (void)hipFree(d_a);
+    (void)hipFree(d_b);
+    if (e != hipSuccess) return fail(TSDF_ERR_HIP, "tsdf_selftest_tile_tables: %s", hipGetErrorString(e));
+    uint64_t bad = 0;
+    for (size_t i = 0; i < per; ++i) bad += std::memcmp(&a[i], &b[i], sizeof(float2)) != 0;
+    *mismatches = bad;
+    return TSDF_OK;
+}
+
 int tsdf_probe_stream(tsdf_volume *v, int32_t non_temporal, int32_t n_iters, float *elapsed_ms)
 {
     if (!v || n_iters <= 0 || !elapsed_ms) return fail(TSDF_ERR_INVALID, "tsdf_probe_stream: bad argument");

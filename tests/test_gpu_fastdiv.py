@@ -2,6 +2,7 @@
 quotient bit for bit wherever the kernel uses it.  Checked on the device against the compiler's
 own division on ~4 billion pseudo-random operand pairs (structured mantissas, zeros, tiny and
 huge numerators, denominators across [2^-60, 2^60])."""
+import numpy as np
 import pytest
 
 from semantic_slam_amd import capi
@@ -36,3 +37,28 @@ def test_truncated_distance_division_is_ieee_exact(cuda, seed):
     operand pairs per seed (quotients around the clamp at 1, structured mantissas, both signs)."""
     bad, first = capi.selftest_fastdiv_band(1 << 30, seed=seed)
     assert bad == 0, f"{bad} mismatches, first: n={first[0]!r} d={first[1]!r} got={first[2]!r} want={first[3]!r}"
+
+
+@pytest.mark.parametrize("h,w", [(480, 640), (481, 643), (97, 130), (768, 1024), (16, 16), (5, 7)])
+def test_tile_table_kernels_agree(cuda, h, w):
+    """The depth tile tables of the classified launches: whole-row strip summary + levels by doubling (what is launched)
+    against one wavefront per tile + levels by scanning, bit for bit -- random depths with invalid, out-of-range, NaN and
+    infinite pixels, with and without a mask, aligned and unaligned buffers."""
+    rng = np.random.default_rng(h * 1000 + w)
+    depth = rng.uniform(0.3, 5.5, (h, w)).astype(np.float32)
+    depth[rng.uniform(0, 1, (h, w)) < 0.02] = 0.0
+    depth[rng.uniform(0, 1, (h, w)) < 0.01] = 7.0
+    depth[rng.uniform(0, 1, (h, w)) < 0.002] = np.nan
+    depth[rng.uniform(0, 1, (h, w)) < 0.002] = np.inf
+    depth[rng.uniform(0, 1, (h, w)) < 0.002] = -1.0
+    depth[: h // 3, : w // 2] = rng.uniform(1.0, 1.2, (h // 3, w // 2)).astype(np.float32)   # a region of all-valid tiles
+    mask = (rng.uniform(0, 1, (h, w)) < 0.8).astype(np.uint8) * 255
+    mask[: h // 4] = 255
+    for off in (0, 1):
+        d_buf = cuda.zeros(h * w + 4, dtype=cuda.float32, device="cuda")
+        m_buf = cuda.zeros(h * w + 4, dtype=cuda.uint8, device="cuda")
+        d_buf[off:off + h * w].copy_(cuda.from_numpy(depth.ravel()))
+        m_buf[off:off + h * w].copy_(cuda.from_numpy(mask.ravel()))
+        cuda.cuda.synchronize()
+        assert capi.selftest_tile_tables(d_buf.data_ptr() + 4 * off, None, h, w) == 0
+        assert capi.selftest_tile_tables(d_buf.data_ptr() + 4 * off, m_buf.data_ptr() + off, h, w) == 0
