@@ -63,6 +63,14 @@ def load():
     if not os.path.isfile(LIB_PATH):
         raise TsdfError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(there is no CPU fallback)")
+    # One HIP runtime per process: PyTorch ships its own libamdhip64, this library links ROCm's.  Whichever is loaded
+    # first serves both (same SONAME); loaded the other way round the process ends up with two runtimes, and the second
+    # one to initialise sees no device (tsdf_create: "no HIP device visible").  Callers hand torch device pointers to this
+    # library anyway, so torch -- when it is installed -- goes first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, f32p, i64p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int64)
     L.tsdf_config_default.argtypes = [C.POINTER(TsdfConfig), C.c_int32, C.c_int32]
