@@ -390,31 +390,48 @@ def main():
 
     # ---- after the timed region, N > 1: the one-voxel halo (RCCL) and the extraction it feeds --------------------
     extraction = None
+    extraction_hung = False
     if world > 1 and not args.no_extract:
-        try:
-            from semantic_slam_amd.sharded import ShardedVolume
-            sv = ShardedVolume(dims, lambda a, b: vol, dist=dist, comm_device=comm_dev)
-            assert (sv.z_begin, sv.z_end) == (zb, ze)
-            fence()
-            t1 = time.perf_counter()
-            halo = sv.halo_exchange()
-            torch.cuda.synchronize()
-            t2 = time.perf_counter()
-            n_x = len(vol.extract_crossings(halo))
-            t3 = time.perf_counter()
-            et = torch.tensor([t2 - t1, t3 - t2, float(n_x)], dtype=torch.float64, device="cpu" if backend == "gloo" else "cuda")
-            dist.all_reduce(et[:2], op=dist.ReduceOp.MAX)
-            dist.all_reduce(et[2:], op=dist.ReduceOp.SUM)
-            extraction = {"halo_exchange_ms": round(float(et[0]) * 1e3, 3), "crossings_ms": round(float(et[1]) * 1e3, 3),
-                          "vertices": int(et[2]), "halo_bytes_per_boundary": 8 * dims[0] * dims[1],
-                          "backend": "rccl (buffers in HBM, device-to-device slice copy, device-resident halo)" if comm_dev == "cuda"
-                                     else "gloo (host buffers)",
-                          "note": "after the timed region: every rank sends its first slice to the rank below (grouped isend/irecv), "
-                                  "then extracts its slab's zero crossings with the received slice as +z neighbour; max over ranks"}
-        except Exception as e:   # noqa: BLE001 -- the headline has been measured: report the failure, keep the line
-            extraction = {"error": repr(e)[:400]}
+        def halo_and_extract():
+            try:
+                torch.cuda.set_device(local_rank)      # the current device is per thread
+                from semantic_slam_amd.sharded import ShardedVolume
+                sv = ShardedVolume(dims, lambda a, b: vol, dist=dist, comm_device=comm_dev)
+                assert (sv.z_begin, sv.z_end) == (zb, ze)
+                fence()
+                t1 = time.perf_counter()
+                halo = sv.halo_exchange()
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                n_x = len(vol.extract_crossings(halo))
+                t3 = time.perf_counter()
+                et = torch.tensor([t2 - t1, t3 - t2, float(n_x)], dtype=torch.float64, device="cpu" if backend == "gloo" else "cuda")
+                dist.all_reduce(et[:2], op=dist.ReduceOp.MAX)
+                dist.all_reduce(et[2:], op=dist.ReduceOp.SUM)
+                return {"halo_exchange_ms": round(float(et[0]) * 1e3, 3), "crossings_ms": round(float(et[1]) * 1e3, 3),
+                        "vertices": int(et[2]), "halo_bytes_per_boundary": 8 * dims[0] * dims[1],
+                        "backend": "rccl (buffers in HBM, device-to-device slice copy, device-resident halo)" if comm_dev == "cuda"
+                                   else "gloo (host buffers)",
+                        "note": "after the timed region: every rank sends its first slice to the rank below (grouped isend/irecv), "
+                                "then extracts its slab's zero crossings with the received slice as +z neighbour; max over ranks"}
+            except Exception as e:   # noqa: BLE001 -- the headline has been measured: report the failure, keep the line
+                return {"error": repr(e)[:400]}
+        # On a thread with a deadline: the headline has been measured, and a wire that never answers (this path has never
+        # run over RCCL -- the build box has one GPU) must not take the line with it.
+        import threading
+        box = {}
+        th = threading.Thread(target=lambda: box.update(r=halo_and_extract()), daemon=True)
+        th.start()
+        th.join(120.0)
+        if th.is_alive():
+            extraction_hung = True
+            extraction = {"error": "halo exchange + extraction did not finish within 120 s; the line is printed without it"}
+        else:
+            extraction = box.get("r")
 
     if rank != 0:
+        if extraction_hung:
+            os._exit(0)          # a collective is stuck on the other thread: nothing to tear down politely
         vol.close()
         if dist is not None:
             dist.destroy_process_group()
@@ -609,6 +626,8 @@ def main():
             line["cpu_reference"] = ref
     print(json.dumps(line))
     sys.stdout.flush()
+    if extraction_hung:
+        os._exit(0)              # see above: the line is out, a collective is stuck on the other thread
     vol.close()
     if dist is not None:
         dist.destroy_process_group()
