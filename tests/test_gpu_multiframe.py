@@ -196,3 +196,31 @@ def test_runs_of_free_space_frames_with_awkward_weights(cuda, oracle, variant):
     assert np.array_equal(w, ref_w), f"{np.count_nonzero(w != ref_w)} weights differ, e.g. {w[w != ref_w][:4]} vs {ref_w[w != ref_w][:4]}"
     assert np.array_equal(t.view(np.uint32), ref_t.view(np.uint32))
     assert ref_w[0] == 5.0 + 38.0 or ref_w[0] == 5.0 + 37.0     # counts moved by the frames that saw the voxel
+
+
+def test_wide_slices_fall_back_to_memory_order(cuda, oracle):
+    """A slice of 4096 x 2048 voxels has 65 536 brick workgroups -- one more than a slow grid dimension holds, so the
+    classified launch goes out in memory order (workgroups along x, slice groups along z) instead of slices fastest.
+    Same bits; claims are made."""
+    dims, vs = (4096, 2048, 8), 0.00025
+    origin = np.array([-dims[0] * vs / 2, -dims[1] * vs / 2, 1.2], np.float32)
+    cfg = capi.make_config(dims, vs, origin)
+    far = float(origin[2]) + dims[2] * vs
+    poses = [synth.identity_pose(), synth.make_pose(synth.rot_z(0.02), [0.003, -0.002, 0.0]), synth.make_pose(synth.rot_y(0.01), [0.0, 0.004, 0.0])]
+    depths = [np.full((480, 640), far + 0.2, np.float32) for _ in poses]
+    depths[1][:, 320:] = float(origin[2]) + 0.5 * dims[2] * vs          # a surface through the right half of the slab
+    depths[2][:240, :] = float(origin[2]) - 0.3                         # in front of the slab: nothing updated up there
+    ref_t, ref_w = oracle.init_grid(dims)
+    for p, d in zip(poses, depths):
+        oracle.integrate(cfg.cam_K, p, d, dims, origin, vs, cfg.trunc_margin, ref_t, ref_w, threads=8)
+    keep = [cuda.from_numpy(d).cuda() for d in depths]
+    with capi.Volume(cfg) as vol:
+        vol.set_kernel_variant(8)
+        assert vol.brick_shape() == (2, 4, 8)
+        vol.shortcut_stats(True)
+        vol.integrate_frames_device([d.data_ptr() for d in keep], np.stack(poses))
+        per_voxel, free, skipped = vol.shortcut_stats(False)
+        t, w = vol.download()
+    assert free > 0 and skipped > 0 and per_voxel > 0 and per_voxel + free + skipped == 3 * (4096 // 8) * (2048 // 4)
+    assert np.array_equal(w, ref_w) and np.array_equal(t.view(np.uint32), ref_t.view(np.uint32))
+    assert ref_w.max() == 3 and ref_w.min() < 3
