@@ -217,3 +217,40 @@ def test_deferred_batch_keeps_call_order_with_borrowed_handles(cuda, oracle):
         batch.integrate_device(d_dev[3].data_ptr(), mp, poses[3])               # D: still collected when the batch goes
     finally:
         batch.close()
+
+
+def test_deferred_batch_of_many_members_on_side_streams(cuda, oracle):
+    """Eight and more members: the members' fused launches of a flush go out on four side streams forked from and joined
+    back into the batch's stream.  Ten members, instance masks, two flushes (35 frames: a full pass + 3) and an observation
+    in between -- every member equal to the oracle."""
+    rng = np.random.default_rng(77)
+    dims, vs = (96, 80, 48), 0.006
+    n_members, n_frames = 10, 35
+    scene = synth.SurfScene((200, 200, 200), 0.004, np.array([-0.4, -0.4, 0.7], np.float32))
+    members = []
+    for i in range(n_members):
+        o = np.array([-0.45 + 0.07 * i, -0.3 + rng.uniform(0, 0.2), 0.7 + rng.uniform(0, 0.5)], np.float32)
+        m = np.zeros((480, 640), np.uint8)
+        r0, c0 = int(rng.integers(0, 200)), int(rng.integers(0, 300))
+        m[r0:r0 + 280, c0:c0 + 340] = 255
+        members.append((o, m))
+    cfgs = [capi.make_config(dims, vs, o, vol_id=i) for i, (o, _) in enumerate(members)]
+    poses = [scene.pose(k % 16, 16) for k in range(n_frames)]
+    depths = [scene.depth(scene.pose(k, 16), quantize=True) for k in range(16)]
+    refs = [oracle.init_grid(dims) for _ in members]
+    d_dev = [cuda.from_numpy(d).cuda() for d in depths]
+    m_dev = [cuda.from_numpy(m).cuda() for _, m in members]
+    with capi.Batch(cfgs) as batch:
+        for k in range(n_frames):
+            batch.integrate_device(d_dev[k % 16].data_ptr(), [m.data_ptr() for m in m_dev], poses[k])
+            for (o, m), (rt, rw), cfg in zip(members, refs, cfgs):
+                oracle.integrate(cfg.cam_K, poses[k], oracle.mask_depth(depths[k % 16], m), dims, o, vs, cfg.trunc_margin, rt, rw, threads=8)
+            if k == 20:     # an observation of one member in the middle of a pass flushes all of them
+                t, w = batch.volumes[3].download()
+                assert np.array_equal(w, refs[3][1]) and np.array_equal(t.view(np.uint32), refs[3][0].view(np.uint32))
+        batch.sync()
+        for vol, (rt, rw) in zip(batch.volumes, refs):
+            t, w = vol.download()
+            assert np.array_equal(w, rw), f"member {vol.cfg.id}: weights differ"
+            assert np.array_equal(t.view(np.uint32), rt.view(np.uint32)), f"member {vol.cfg.id}: TSDF differs"
+    assert sum(float(rw.sum()) for _, rw in refs) > 100000
