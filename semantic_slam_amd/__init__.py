@@ -5,7 +5,6 @@ csrc/) plus the C++ drop-in classes in include/tsdf.hpp / include/TSDFfusion.hpp
 Python package is the thin host-side mirror used by tests and bench.py:
 
     capi     ctypes binding of the C ABI (no fallback: raises if the library is missing)
-    tsdf     `TSDF` class with the reference's method names (Python mirror of include/tsdf.hpp)
     ingest   keyframe poses / associations saved by the SLAM front-end
     sharded  z-slab sharding of one grid over ranks / devices
     synth    synthetic depth + pose workloads (numpy)

@@ -147,26 +147,3 @@ def test_tsdffusion_native_backend(cuda, oracle, tmp_path, surface):
     same = np.all(rec[:, 24:] == want_rgb, axis=1)
     assert same.mean() > 0.999, "vertex colours must be the nearest voxel's (ties at .5 may round either way)"
     assert len(np.unique(want_rgb, axis=0)) > 50
-
-
-def test_python_mirror_of_class_tsdf(cuda, oracle, tmp_path):
-    """semantic_slam_amd.tsdf.TSDF: same names and behaviour as the C++ class (default grid, files on close)."""
-    from semantic_slam_amd.tsdf import TSDF
-    dims, vs = (200, 200, 200), 0.004
-    origin = np.array([-0.4, -0.4, 0.7], np.float32)
-    scene = synth.SurfScene(dims, vs, origin)
-    base = synth.identity_pose()
-    t = TSDF(480, 640, 5, base, origin)
-    assert t.voxel_grid_TSDF[0] == 1.0 and t.voxel_grid_weight.sum() == 0
-    ref_t, ref_w = oracle.init_grid(dims)
-    for k in range(2):
-        c2w = scene.pose(k, n=8)
-        d = scene.depth(c2w)
-        t.Integrate(d, c2w)
-        oracle.integrate(synth.TUM_K, c2w, d, dims, origin, vs, float(np.float32(vs) * np.float32(5)), ref_t, ref_w)
-    t.Download()
-    assert np.array_equal(t.voxel_grid_weight, ref_w) and np.array_equal(t.voxel_grid_TSDF, ref_t)
-    t.close(str(tmp_path))
-    oracle.save_bin(str(tmp_path / "want.bin"), ref_t, dims, origin, vs, float(np.float32(vs) * np.float32(5)))
-    assert (tmp_path / "tsdf5.bin").read_bytes() == (tmp_path / "want.bin").read_bytes()
-    assert (tmp_path / "tsdf5.ply").stat().st_size > 100
