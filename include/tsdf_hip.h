@@ -347,6 +347,8 @@ int tsdf_set_kernel_variant(tsdf_volume *vol, int32_t variant);
  */
 int tsdf_set_brick_shape(tsdf_volume *vol, int32_t quads, int32_t rows, int32_t slices);
 int tsdf_brick_shape(const tsdf_volume *vol, int32_t shape_out[3]);
+/* The shape tsdf_create would choose for this grid (host arithmetic only: needs no device). */
+int tsdf_default_brick_shape(const tsdf_config *cfg, int32_t shape_out[3]);
 
 /*
  * Integrate AND label fusion of a known sequence of frames in the same passes over the volume: identical to

@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "tsdf_sync", "tsdf_download", "tsdf_copy_slices", "tsdf_upload", "tsdf_refresh_summary", "tsdf_device_ptrs", "tsdf_slab_voxels", "tsdf_frames_per_launch", "tsdf_shortcut_stats", "tsdf_classification_info",
     "tsdf_get_config", "tsdf_last_cam2base", "tsdf_set_stream", "tsdf_get_stream",
     "tsdf_count_surface", "tsdf_extract_surface", "tsdf_extract_crossings", "tsdf_extract_mesh", "tsdf_save_mesh_ply", "tsdf_save_mesh_welded_ply", "tsdf_save_ply", "tsdf_save_bin", "tsdf_load_bin", "tsdf_save_state", "tsdf_load_state",
-    "tsdf_integrate_sequence_timed", "tsdf_integrate_frames_timed", "tsdf_probe_graph_replay", "tsdf_probe_stream", "tsdf_selftest_fastdiv", "tsdf_selftest_fastdiv_band", "tsdf_selftest_round", "tsdf_selftest_tile_tables", "tsdf_set_kernel_variant", "tsdf_set_brick_shape", "tsdf_brick_shape", "tsdf_last_error",
+    "tsdf_integrate_sequence_timed", "tsdf_integrate_frames_timed", "tsdf_probe_graph_replay", "tsdf_probe_stream", "tsdf_selftest_fastdiv", "tsdf_selftest_fastdiv_band", "tsdf_selftest_round", "tsdf_selftest_tile_tables", "tsdf_set_kernel_variant", "tsdf_set_brick_shape", "tsdf_brick_shape", "tsdf_default_brick_shape", "tsdf_last_error",
     "tsdf_version", "tsdf_multiply_matrix", "tsdf_invert_matrix",
     "tsdf_labels_enable", "tsdf_compose_labels", "tsdf_integrate_labels_device", "tsdf_integrate_frames_labels_device",
     "tsdf_download_labels",
@@ -123,6 +123,7 @@ def load():
     L.tsdf_set_kernel_variant.argtypes = [vp, C.c_int32]
     L.tsdf_set_brick_shape.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
     L.tsdf_brick_shape.argtypes = [vp, C.POINTER(C.c_int32)]
+    L.tsdf_default_brick_shape.argtypes = [C.POINTER(TsdfConfig), C.POINTER(C.c_int32)]
     L.tsdf_last_error.restype = C.c_char_p
     L.tsdf_version.restype = C.c_char_p
     L.tsdf_multiply_matrix.argtypes = [vp, vp, vp]
@@ -249,6 +250,13 @@ def selftest_round(device=0):
     bad = (C.c_float * 4)()
     check(load().tsdf_selftest_round(device, C.byref(cnt), bad), "tsdf_selftest_round")
     return cnt.value, list(bad)
+
+
+def default_brick_shape(cfg):
+    """(quads, rows, slices) of the wavefront brick tsdf_create would choose for this grid; host arithmetic only."""
+    out = (C.c_int32 * 3)()
+    check(load().tsdf_default_brick_shape(C.byref(cfg), out), "tsdf_default_brick_shape")
+    return tuple(out)
 
 
 def selftest_tile_tables(depth_ptr, mask_ptr, im_height, im_width, max_depth=6.0, device=0):

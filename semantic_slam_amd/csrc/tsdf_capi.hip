@@ -207,16 +207,16 @@ bool brick_shape_ok(const tsdf_config &c, int q, int r, int s)
     return c.dim_x % 4 == 0 && q >= 1 && r >= 1 && s >= 1 && q * r * s <= 64 && (c.dim_x / 4) % q == 0;
 }
 
-void choose_brick(tsdf_volume *v)
+// (host arithmetic only: also behind tsdf_default_brick_shape, which needs no device)
+void choose_brick_for(const tsdf_config &c, int &bq, int &br, int &bs)
 {
-    const tsdf_config &c = v->cfg;
-    v->brick_q = 0; v->brick_r = 0; v->brick_s = 1;
+    bq = 0; br = 0; bs = 1;
     if (c.dim_x % 4 != 0) return;
     const int quads = c.dim_x / 4;
     if (const char *e = std::getenv("TSDF_BRICK3D")) {      // A/B knob: "q,r,s"
         int q = 0, r = 0, sl = 0;
         if (std::sscanf(e, "%d,%d,%d", &q, &r, &sl) == 3 && brick_shape_ok(c, q, r, sl)) {
-            v->brick_q = q; v->brick_r = r; v->brick_s = sl;
+            bq = q; br = r; bs = sl;
             return;
         }
     }
@@ -235,10 +235,12 @@ void choose_brick(tsdf_volume *v)
             const int r = std::min(64 / (q * sl), std::max(c.dim_y, 1));
             const double X = 4.0 * q, Y = r, Z = sl;
             const double cost = (X + 8.0) * (Y + 8.0) * (Z + 10.0) / (X * Y * Z) * (1.0 + 0.25 / q) * 64.0 / (q * r * sl);
-            if (cost < best) { best = cost; v->brick_q = q; v->brick_r = r; v->brick_s = sl; }
+            if (cost < best) { best = cost; bq = q; br = r; bs = sl; }
         }
     }
 }
+
+void choose_brick(tsdf_volume *v) { choose_brick_for(v->cfg, v->brick_q, v->brick_r, v->brick_s); }
 
 tsdfk::IntegrateParams make_params(const tsdf_volume *v, const float *depth_dev,
                                    const uint8_t *mask_dev, const float *c2b, int vx)
@@ -1564,6 +1566,17 @@ int tsdf_set_brick_shape(tsdf_volume *v, int32_t quads, int32_t rows, int32_t sl
         return fail(TSDF_ERR_INVALID, "tsdf_set_brick_shape: %d quads x %d rows x %d slices: needs quads * rows * slices <= 64 and "
                     "quads dividing dim_x / 4 = %d", quads, rows, slices, v->cfg.dim_x / 4);
     v->brick_q = quads; v->brick_r = rows; v->brick_s = slices;
+    return TSDF_OK;
+}
+
+int tsdf_default_brick_shape(const tsdf_config *cfg, int32_t shape_out[3])
+{
+    if (!cfg || !shape_out) return fail(TSDF_ERR_INVALID, "tsdf_default_brick_shape: NULL argument");
+    if (cfg->dim_x <= 0 || cfg->dim_y <= 0 || cfg->z_end < cfg->z_begin)
+        return fail(TSDF_ERR_INVALID, "tsdf_default_brick_shape: bad grid");
+    int q, r, s;
+    choose_brick_for(*cfg, q, r, s);
+    shape_out[0] = q; shape_out[1] = q ? r : 0; shape_out[2] = q ? s : 0;
     return TSDF_OK;
 }
 
