@@ -20,8 +20,10 @@ and two full launches) the K-step sequence is repeated until at least 0.3 s of d
 a barrier + torch.cuda.synchronize() on both sides; ms_per_step = wall / (K x repeats), max over ranks; HIP events
 on the handle's stream give the kernel time.  For N > 1 every rank owns one z-slab (no data-path collective; by
 default WEAK scaling: each rank's slab holds as many voxels as the whole N = 1 grid); after the timed region the
-ranks run the one-voxel halo exchange (RCCL) and the halo-fed extraction once and report its time.  Launch with
-torch.distributed.run as the driver does.  Rank 0 prints one JSON line.
+ranks run the one-voxel halo exchange (RCCL) and the halo-fed extraction once and report its time; if that step does
+not come back within 120 s, or raises, the line is still printed (with `extraction_hung` / `extraction.error`) and every
+rank exits non-zero (3 = hung, 4 = failed), so a dead wire shows in the record.  Launch with torch.distributed.run as
+the driver does.  Rank 0 prints one JSON line.
 """
 import argparse
 import csv
@@ -126,18 +128,7 @@ class Workload:
         if name in ("ssurf", "traj") and (noise_mm > 0 or holes > 0):
             # a sensor's imperfections (Gaussian noise, sigma 2 mm; dropouts as zero blocks), then the
             # 1/5000 m quantisation again
-            rng = np.random.default_rng(1234)
-            out = []
-            for d in self.depths:
-                d = d.copy()
-                if noise_mm > 0:
-                    d = np.where(d > 0, d + rng.normal(0.0, noise_mm * 1e-3, d.shape).astype(np.float32), d)
-                    d = (np.round(d * 5000.0) / 5000.0).astype(np.float32)
-                if holes > 0:
-                    drop = rng.uniform(0, 1, (d.shape[0] // 8, d.shape[1] // 8)) < holes
-                    d[np.kron(drop, np.ones((8, 8), bool))] = 0.0
-                out.append(np.ascontiguousarray(d, np.float32))
-            self.depths = out
+            self.depths = synth.sensor_imperfections(self.depths, noise_mm, holes)
             self.desc += f"; Gaussian noise sigma {noise_mm:g} mm, {holes * 100:g} % of the image dropped in 8 x 8 blocks"
         self.n_pose = len(self.poses)
 
@@ -429,12 +420,18 @@ def main():
         else:
             extraction = box.get("r")
 
+    # A dead wire must be visible in the driver's record: the line is still printed (the timed region is done), but the
+    # process ends with a non-zero code -- 3 = the halo exchange / extraction never came back (a stuck collective),
+    # 4 = it failed with an error -- on every rank.
+    extraction_failed = extraction is not None and "error" in extraction
     if rank != 0:
         if extraction_hung:
-            os._exit(0)          # a collective is stuck on the other thread: nothing to tear down politely
+            os._exit(3)          # a collective is stuck on the other thread: nothing to tear down politely
         vol.close()
         if dist is not None:
             dist.destroy_process_group()
+        if extraction_failed:
+            sys.exit(4)
         return
 
     # ---- roofline of the dominant kernel on this rank -------------------------------------------------------------
@@ -508,8 +505,14 @@ def main():
                      "note": "per-rank slab launch; kernel_ms = HIP-event time of the timed region (events on the handle's "
                              "stream) / launches; achieved = algorithmic_bytes_per_launch / kernel_ms"},
     }
+    if world > 1:
+        # what a SCALE record must show: how many ranks the communicator saw, through which backend, and what the halo costs
+        line["multi_gpu"] = {"world": world, "backend": "rccl (torch.distributed 'nccl')" if backend != "gloo" else "gloo",
+                             "comm_device": comm_dev, "halo_bytes_per_boundary": 8 * dims[0] * dims[1],
+                             "data_path_collectives": 0, "halo_and_extraction_ran": extraction is not None and not extraction_failed}
     if extraction is not None:
         line["extraction"] = extraction
+        line["extraction_hung"] = bool(extraction_hung)
     extras = world == 1 and args.emulate_world <= 1 and not args.no_extras
 
     def timed_leg(v, start_warm, n_warm_, n_block, min_ms=150.0):
@@ -627,10 +630,12 @@ def main():
     print(json.dumps(line))
     sys.stdout.flush()
     if extraction_hung:
-        os._exit(0)              # see above: the line is out, a collective is stuck on the other thread
+        os._exit(3)              # see above: the line is out, a collective is stuck on the other thread -> rc 3
     vol.close()
     if dist is not None:
         dist.destroy_process_group()
+    if extraction_failed:
+        sys.exit(4)              # the line is out; the halo exchange / extraction raised -> rc 4
 
 
 if __name__ == "__main__":

@@ -175,6 +175,27 @@ def surf_volume(dim, voxel_size, z0=1.0):
 
 
 # --------------------------------------------------------------------------------------
+# a sensor's imperfections (Gaussian noise, sigma 2 mm; dropouts as zero blocks)
+# --------------------------------------------------------------------------------------
+def sensor_imperfections(depths, noise_mm=0.0, holes=0.0, seed=1234):
+    """The frames through zero-mean Gaussian depth noise (sigma in mm, valid pixels only, re-quantised at the TUM factor
+    1/5000 m) and dropouts (the given fraction of the image lost to invalid, i.e. zero, 8 x 8 pixel blocks), one
+    generator for the whole sequence.  Returns new contiguous float32 frames."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for d in depths:
+        d = d.copy()
+        if noise_mm > 0:
+            d = np.where(d > 0, d + rng.normal(0.0, noise_mm * 1e-3, d.shape).astype(np.float32), d)
+            d = (np.round(d * 5000.0) / 5000.0).astype(np.float32)
+        if holes > 0:
+            drop = rng.uniform(0, 1, (d.shape[0] // 8, d.shape[1] // 8)) < holes
+            d[np.kron(drop, np.ones((8, 8), bool))] = 0.0
+        out.append(np.ascontiguousarray(d, np.float32))
+    return out
+
+
+# --------------------------------------------------------------------------------------
 # random rigid poses for parity tests
 # --------------------------------------------------------------------------------------
 def random_pose(rng, max_angle=0.3, max_shift=0.3):

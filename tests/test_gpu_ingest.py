@@ -5,6 +5,7 @@ import os
 import numpy as np
 import pytest
 
+import whole_volume as wv
 from semantic_slam_amd import capi, ingest, synth
 
 pytestmark = pytest.mark.gpu
@@ -37,82 +38,67 @@ def test_u16_depth_on_device_equals_host_preparation(cuda, oracle, steps):
 def test_config2_1024_cube_on_the_fr3_trajectory(cuda, oracle):
     """BASELINE configs[2]: 1024^3 @ 2 mm on one MI355X (8.6 GB resident), camera poses = keyframes of
     the reference's saved fr3_office run (base = first keyframe), depth rendered per pose with TUM
-    quantisation.  The oracle checks three 6-slice slabs bit for bit; the whole grid is checked
-    through properties."""
-    Twc = ingest.pose_inverse(np.load(GOLD)["Tcw"])
-    base = Twc[0].ravel()
-    D, vs = 1024, 0.002
-    dims = (D, D, D)
-    origin = np.array([-1.024, -1.024, 0.6], np.float32)
-    cfg = capi.make_config(dims, vs, origin, base2world=base)
-    scene = synth.SurfScene(dims, vs, origin)
-    frames = []
-    for k in (0, 40, 90, 150):
-        c2b = oracle.cam2base(base, Twc[k].ravel())
-        frames.append((Twc[k].ravel(), c2b, scene.depth(c2b, quantize=True)))
+    quantisation, given as HOST frames through tsdf_integrate (the reference's own call).  The pose
+    composition is checked against the oracle's; every voxel of the grid against the reference's own
+    kernel on the device (tests/whole_volume.py), or -- where that build is absent -- three 6-slice
+    slabs against the oracle."""
+    T = wv.fr3_trajectory(oracle)
+    cfg, dims, D = T["cfg"], T["dims"], 1024
+    ks = (0, 40, 90, 150)
     with capi.Volume(cfg) as vol:
-        for c2w, c2b, depth in frames:
-            vol.integrate(depth, c2w)
-            assert np.array_equal(vol.last_cam2base(), c2b)
+        for k in ks:
+            vol.integrate(T["depths"][k], T["poses"][k])
+            assert np.array_equal(vol.last_cam2base(), T["c2b"][k])
         n_surface = vol.count_surface(0.9)
-        for zb in (0, 509, D - 6):
-            st, sw = oracle.init_grid(dims, zb, zb + 6)
-            n = 0
-            for _, c2b, depth in frames:
-                n += oracle.integrate(cfg.cam_K, c2b, depth, dims, origin, vs, cfg.trunc_margin, st, sw,
-                                      z_begin=zb, z_end=zb + 6)
-            gt, gw = vol.copy_slices(zb, 6)
-            assert np.array_equal(gw, sw) and np.array_equal(gt.view(np.uint32), st.view(np.uint32))
+        if wv.available():
+            dev = [cuda.from_numpy(T["depths"][k]).cuda() for k in ks]
+            ref_t, ref_w = wv.replay(cuda, "fr3_1024_four", cfg.cam_K, dims, cfg.origin, cfg.voxel_size, cfg.trunc_margin,
+                                     [T["c2b"][k] for k in ks], dev)
+            wv.assert_volume_equals_reference(cuda, "fr3 keyframes 0/40/90/150 into 1024^3, host frames", vol, ref_t, ref_w, dims)
+            wv.drop("fr3_1024_four")
+            del ref_t, ref_w
+        else:
+            for zb in (0, 509, D - 6):
+                st, sw = oracle.init_grid(dims, zb, zb + 6)
+                for k in ks:
+                    oracle.integrate(cfg.cam_K, T["c2b"][k], T["depths"][k], dims, cfg.origin, cfg.voxel_size, cfg.trunc_margin,
+                                     st, sw, z_begin=zb, z_end=zb + 6)
+                gt, gw = vol.copy_slices(zb, 6)
+                assert np.array_equal(gw, sw) and np.array_equal(gt.view(np.uint32), st.view(np.uint32))
         mid_t, mid_w = vol.copy_slices(480, 64)
     assert n_surface > 1_000_000
-    assert mid_w.max() <= len(frames) and np.all(mid_w == np.round(mid_w))
+    assert mid_w.max() <= len(ks) and np.all(mid_w == np.round(mid_w))
     assert mid_t.min() >= -1.0 and mid_t.max() <= 1.0 and np.count_nonzero(mid_t < 1.0) > 10000
-
-
-_TRAJ = {}
-
-
-def _trajectory(oracle):
-    """Poses, relative poses and rendered depth frames of the 194 keyframes (rendered once per session) and the oracle's
-    replay of two 3-slice slabs."""
-    if not _TRAJ:
-        Twc = ingest.pose_inverse(np.load(GOLD)["Tcw"])
-        base = Twc[0].ravel()
-        D, vs = 1024, 0.002
-        dims = (D, D, D)
-        origin = np.array([-1.024, -1.024, 0.6], np.float32)
-        cfg = capi.make_config(dims, vs, origin, base2world=base)
-        scene = synth.SurfScene(dims, vs, origin)
-        n = len(Twc)
-        c2b = [oracle.cam2base(base, Twc[k].ravel()) for k in range(n)]
-        depths = [scene.depth(c2b[k], quantize=True) for k in range(n)]
-        slabs = {}
-        for zb in (300, 700):
-            st, sw = oracle.init_grid(dims, zb, zb + 3)
-            for k in range(n):
-                oracle.integrate(cfg.cam_K, c2b[k], depths[k], dims, origin, vs, cfg.trunc_margin, st, sw,
-                                 z_begin=zb, z_end=zb + 3, threads=8)
-            slabs[zb] = (st, sw)
-        _TRAJ.update(Twc=Twc, cfg=cfg, depths=depths, slabs=slabs, n=n)
-    return _TRAJ
 
 
 @pytest.mark.parametrize("variant", [0, 7, 8])
 def test_config2_full_fr3_trajectory_fused(cuda, oracle, variant):
     """All 194 keyframes of the reference's saved fr3_office run into a 1024^3 @ 2 mm volume through
     tsdf_integrate_frames_device (up to 32 frames per pass over the 8.6 GB volume), every frame's depth
-    resident in HBM.  Two 3-slice slabs are replayed by the oracle frame by frame and must match bit
-    for bit; the frame count bounds every weight.  Patch classification decided per launch (0), never (7), always (8)."""
-    T = _trajectory(oracle)
-    n = T["n"]
-    with capi.Volume(T["cfg"]) as vol:
+    resident in HBM; patch classification decided per launch (0), never (7), always (8).  EVERY voxel
+    (2^30 of them) against the reference's own kernel replaying the same 194 frames over the whole grid on
+    the device; one 3-slice slab is also replayed by the CPU oracle (the check that remains where the
+    reference build is absent)."""
+    T = wv.fr3_trajectory(oracle, cuda)
+    n, cfg, dims = T["n"], T["cfg"], T["dims"]
+    if "slab" not in T:
+        zb = 300
+        st, sw = oracle.init_grid(dims, zb, zb + 3)
+        for k in range(n):
+            oracle.integrate(cfg.cam_K, T["c2b"][k], T["depths"][k], dims, cfg.origin, cfg.voxel_size, cfg.trunc_margin, st, sw,
+                             z_begin=zb, z_end=zb + 3, threads=8)
+        T["slab"] = (zb, st, sw)
+    with capi.Volume(cfg) as vol:
         vol.set_kernel_variant(variant)
-        dev = [cuda.from_numpy(d).cuda() for d in T["depths"]]
-        vol.integrate_frames_device([d.data_ptr() for d in dev], np.stack([M.ravel() for M in T["Twc"]]))
+        vol.integrate_frames_device([d.data_ptr() for d in T["dev"]], T["poses"])
         vol.sync()
-        for zb, (st, sw) in T["slabs"].items():
-            gt, gw = vol.copy_slices(zb, 3)
-            assert sw.max() > 20, "the trajectory should see these slices many times"
-            assert np.array_equal(gw, sw) and np.array_equal(gt.view(np.uint32), st.view(np.uint32))
+        zb, st, sw = T["slab"]
+        gt, gw = vol.copy_slices(zb, 3)
+        assert sw.max() > 20, "the trajectory should see these slices many times"
+        assert np.array_equal(gw, sw) and np.array_equal(gt.view(np.uint32), st.view(np.uint32))
+        if wv.available():
+            ref_t, ref_w = wv.fr3_reference(cuda, oracle)
+            assert float(ref_w.max()) > 100 and float((ref_w > 0).sum()) / ref_w.numel() > 0.05
+            wv.assert_volume_equals_reference(cuda, f"fr3 trajectory, 194 keyframes into 1024^3 / variant {variant}", vol, ref_t, ref_w, dims)
         _, w_mid = vol.copy_slices(500, 8)
     assert w_mid.max() <= n and np.all(w_mid == np.round(w_mid))
