@@ -72,6 +72,9 @@ def parse():
     ap.add_argument("--noise-mm", type=float, default=0.0, help="ssurf / traj: zero-mean Gaussian depth noise, sigma in mm (SURVEY.md 8d), rng seed 1234")
     ap.add_argument("--holes", type=float, default=0.0, help="ssurf / traj: fraction of the image lost to invalid (zero) 8 x 8 pixel blocks, like a real sensor's dropouts")
     ap.add_argument("--voxel-mm", type=float, default=0.0, help="voxel size in mm (default: 5 at 512, 2 at 1024, else 2560 / grid)")
+    ap.add_argument("--tum-dir", default="", help="traj: directory of the TUM fr3_office sequence (holding depth/<stamp>.png as "
+                    "result/rgbd/associations.txt names them); when it exists the keyframes' real 16-bit depth frames are integrated "
+                    "(value / 5000 m) instead of the rendered ones.  No dataset ships with the repository and none is fetched.")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
     a = ap.parse_args()
@@ -88,7 +91,7 @@ def parse():
 class Workload:
     """origin, truncation margin, base pose, the cam2world stream and the depth frame(s) it comes with."""
 
-    def __init__(self, name, dims, vs, noise_mm=0.0, holes=0.0):
+    def __init__(self, name, dims, vs, noise_mm=0.0, holes=0.0, tum_dir=""):
         from semantic_slam_amd import synth
         self.name, self.dims, self.vs = name, dims, vs
         self.trunc = None            # None = the reference's 5 x voxel
@@ -122,9 +125,18 @@ class Workload:
             ok, binv = capi.invert_matrix(self.base2world)
             self.poses = np.stack([T.ravel() for T in Twc])
             # what the camera sees from each keyframe: rendered from the relative pose the library will compose
-            self.depths = [scene.depth(capi.multiply_matrix(binv, p), quantize=True) for p in self.poses]
-            self.desc = (f"the {len(self.poses)} keyframe poses of the reference's saved fr3_office run (result/rgbd/bundle.txt), "
-                         "base = first keyframe, sphere + wall depth re-rendered per pose, quantised at 1/5000 m")
+            names = [str(x) for x in np.load(gold, allow_pickle=False)["depth_names"]]
+            if tum_dir and all(os.path.isfile(os.path.join(tum_dir, nm)) for nm in names):
+                # the sequence is there: the keyframes' own depth frames, raw 16-bit / 5000 (config/TUM3.yaml:34)
+                scale = np.float32(1.0) / np.float32(5000.0)
+                self.depths = [np.ascontiguousarray(ingest.load_depth_png(os.path.join(tum_dir, nm)).astype(np.float32) * scale) for nm in names]
+                self.desc = (f"the {len(self.poses)} keyframes of the reference's saved fr3_office run (result/rgbd/bundle.txt, "
+                             f"associations.txt): poses from the bundle file, base = first keyframe, REAL depth frames from {tum_dir}")
+            else:
+                self.depths = [scene.depth(capi.multiply_matrix(binv, p), quantize=True) for p in self.poses]
+                self.desc = (f"the {len(self.poses)} keyframe poses of the reference's saved fr3_office run (result/rgbd/bundle.txt), "
+                             "base = first keyframe, sphere + wall depth re-rendered per pose, quantised at 1/5000 m"
+                             + ("" if not tum_dir else f" (--tum-dir {tum_dir} does not hold the named depth frames)"))
         if name in ("ssurf", "traj") and (noise_mm > 0 or holes > 0):
             # a sensor's imperfections (Gaussian noise, sigma 2 mm; dropouts as zero blocks), then the
             # 1/5000 m quantisation again
@@ -302,7 +314,7 @@ def main():
     comm_dev = "cpu" if backend == "gloo" else "cuda"
 
     dims, vs, part_world = grid_for(args, world)
-    W = Workload(args.workload, dims, vs, args.noise_mm, args.holes)
+    W = Workload(args.workload, dims, vs, args.noise_mm, args.holes, args.tum_dir)
     D = args.grid
 
     # z-slab of this rank (ref layout is z-major, so a slab is one contiguous range)

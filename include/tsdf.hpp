@@ -76,7 +76,9 @@ class TSDF
 	TSDF(const TSDF &);             // one object owns one device volume (the reference never copies it)
 	TSDF &operator=(const TSDF &);
 	void init();
+	int download_mirrors();
 	void fail(const char *what, int line) const;
+	void fail_in_destructor(const char *what, int line) const;   // never throws (ThrowOnError: prints and goes on)
 	long long voxels() const;
 	tsdf_config cfg_;
 	tsdf_volume *vol_;

@@ -183,6 +183,13 @@ int32_t tsdf_frames_per_launch(const tsdf_volume *vol);
  */
 int tsdf_shortcut_stats(tsdf_volume *vol, int32_t enable, uint64_t counts_out[3]);
 /*
+ * More of the same, for the classified fused launches' brick work list (csrc/tsdf_multiframe.hip.h, classify_brick_list),
+ * accumulated while the counters of tsdf_shortcut_stats are enabled: {super-bricks every frame skipped, bricks put on the
+ * work list, of those: bricks whose super-brick left frames undecided (they classify themselves), of those: bricks every
+ * frame skipped after all}.  Synchronises the stream; does not reset.
+ */
+int tsdf_brick_list_stats(tsdf_volume *vol, uint64_t counts_out[4]);
+/*
  * State of the per-launch decision whether to classify (default kernel variant): info_out[0] = fraction of the
  * workgroup-frames the last counted launch claimed (-1 before the first read-back), info_out[1] = launches that have
  * gone without classification since the last one that classified.  Synchronises the stream.

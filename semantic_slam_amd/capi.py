@@ -19,7 +19,7 @@ ABI_SYMBOLS = [
     "tsdf_integrate_u16", "tsdf_convert_depth_u16", "tsdf_set_deferral",
     "tsdf_integrate_device", "tsdf_integrate_cam2base", "tsdf_integrate_masked_device",
     "tsdf_integrate_frames_device",
-    "tsdf_sync", "tsdf_download", "tsdf_copy_slices", "tsdf_upload", "tsdf_refresh_summary", "tsdf_device_ptrs", "tsdf_slab_voxels", "tsdf_frames_per_launch", "tsdf_shortcut_stats", "tsdf_classification_info",
+    "tsdf_sync", "tsdf_download", "tsdf_copy_slices", "tsdf_upload", "tsdf_refresh_summary", "tsdf_device_ptrs", "tsdf_slab_voxels", "tsdf_frames_per_launch", "tsdf_shortcut_stats", "tsdf_brick_list_stats", "tsdf_classification_info",
     "tsdf_get_config", "tsdf_last_cam2base", "tsdf_set_stream", "tsdf_get_stream",
     "tsdf_count_surface", "tsdf_extract_surface", "tsdf_extract_crossings", "tsdf_extract_mesh", "tsdf_save_mesh_ply", "tsdf_save_mesh_welded_ply", "tsdf_save_ply", "tsdf_save_bin", "tsdf_load_bin", "tsdf_save_state", "tsdf_load_state",
     "tsdf_integrate_sequence_timed", "tsdf_integrate_frames_timed", "tsdf_probe_graph_replay", "tsdf_probe_stream", "tsdf_selftest_fastdiv", "tsdf_selftest_fastdiv_band", "tsdf_selftest_round", "tsdf_selftest_tile_tables", "tsdf_set_kernel_variant", "tsdf_set_brick_shape", "tsdf_brick_shape", "tsdf_default_brick_shape", "tsdf_last_error",
@@ -97,6 +97,7 @@ def load():
     L.tsdf_frames_per_launch.restype = C.c_int32
     L.tsdf_shortcut_stats.argtypes = [vp, C.c_int32, vp]
     L.tsdf_classification_info.argtypes = [vp, vp]
+    L.tsdf_brick_list_stats.argtypes = [vp, vp]
     L.tsdf_get_config.argtypes = [vp, C.POINTER(TsdfConfig)]
     L.tsdf_last_cam2base.argtypes = [vp, vp]
     L.tsdf_set_stream.argtypes = [vp, vp]
@@ -308,6 +309,13 @@ class Volume:
         """(per-voxel, free-space, skipped) wavefront-frame counts since the counters were enabled; then (re)arm or stop."""
         out = (C.c_uint64 * 3)()
         check(self.lib.tsdf_shortcut_stats(self._h, 1 if enable else 0, out), "tsdf_shortcut_stats")
+        return tuple(int(x) for x in out)
+
+    def brick_list_stats(self):
+        """(super-bricks every frame skipped, bricks on the work list, of those left to classify themselves, of those skipped
+        after all) since shortcut_stats(True)."""
+        out = (C.c_uint64 * 4)()
+        check(self.lib.tsdf_brick_list_stats(self._h, out), "tsdf_brick_list_stats")
         return tuple(int(x) for x in out)
 
     def classification_info(self):

@@ -12,6 +12,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -116,6 +117,9 @@ struct tsdf_volume {
     bool flags_known_zero;
     unsigned int *d_super;       // per super-brick frame words of the current fused brick launch (classify_superbricks)
     size_t super_words;
+    uint4 *d_work;               // work list of the current fused brick launch: {brick, slice group, free frames, skipped frames}
+    size_t work_entries;         // per live brick (classify_brick_list); capacity = every brick of the slab
+    int64_t work_nsuper, work_bucket_supers;   // super-bricks of the shape the list was sized for; most of them in one sub-list
     // depth tile summaries of the frames of one fused launch (allocated on first use), optional counters
     float2 *d_tiles;
     unsigned int *d_shortcut_stats;
@@ -370,7 +374,7 @@ constexpr int64_t kClassifyMinVoxels = 48000000;
 bool classify_one_frame(const tsdf_volume *v, int64_t launch_voxels)
 {
     if (v->variant == 7) return false;
-    return v->variant == 8 || v->variant == 12 || launch_voxels >= kClassifyMinVoxels;
+    return v->variant == 8 || v->variant == 12 || v->variant == 13 || launch_voxels >= kClassifyMinVoxels;
 }
 
 // Depth tile tables (summary + sparse table, tsdf_multiframe.hip.h) of n images depth[i] x mask[i] into tables[i], queued
@@ -399,7 +403,7 @@ int build_tile_tables(hipStream_t stream, const tsdf_config &c, const tsdfk::Int
             hipLaunchKernelGGL(tsdfk::tile_sparse_table, dim3((unsigned)tile_levels_host(p.tiles_w), m), dim3(256), 0, stream, tp.tiles,
                                p.tiles_w, p.tiles_h, k == 0 ? zero_me : (unsigned long long *)nullptr);
         } else {
-            if (zero_me && k == 0) HIP_TRY(hipMemsetAsync(zero_me, 0, sizeof(unsigned long long), stream));
+            if (zero_me && k == 0) HIP_TRY(hipMemsetAsync(zero_me, 0, tsdfk::kCounterBytes, stream));
             hipLaunchKernelGGL(tsdfk::tile_sparse_table_scan, dim3((unsigned)tile_levels_host(p.tiles_w), m), dim3(256), 0, stream, tp.tiles,
                                p.tiles_w, p.tiles_h);
         }
@@ -524,6 +528,17 @@ int rebuild_summary(tsdf_volume *v)
 int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *const *masks_dev, const float *c2b, int n,
                  const uint16_t *const *label_ims = nullptr, const float *const *score_ims = nullptr);
 
+// Claimed share of the launch whose counter block has arrived in h_claims: (free << 32 | skipped) per bucket, added up.
+double claims_read_back(const tsdf_volume *v)
+{
+    double claimed = 0.0;
+    for (int b = 0; b < tsdfk::kListBuckets; ++b) {
+        const unsigned long long w = v->h_claims[(size_t)b * (tsdfk::kBucketStride / sizeof(unsigned long long)) + 1];
+        claimed += (double)(w >> 32) + (double)(w & 0xffffffffull);
+    }
+    return v->claims_total > 0 ? claimed / v->claims_total : 0.0;
+}
+
 // Queue one Integrate launch.  Shapes are validated at tsdf_create, so the grid covers exactly
 // the slab and every access stays inside the two allocations.
 int launch_integrate(tsdf_volume *v, const float *depth_dev, const uint8_t *mask_dev,
@@ -534,7 +549,7 @@ int launch_integrate(tsdf_volume *v, const float *depth_dev, const uint8_t *mask
     if (nz == 0) return TSDF_OK;  // empty slab: nothing to do
     std::memcpy(v->last_cam2base, c2b, sizeof v->last_cam2base);
     int variant = v->variant;
-    if (variant == 0 || (variant >= 3 && variant <= 12)) variant = kDefaultTile;
+    if (variant == 0 || (variant >= 3 && variant <= 13)) variant = kDefaultTile;
     if (c.dim_x % 4 != 0) variant = 1;  // rows are not 16-byte aligned: scalar kernel
     if (v->flat && variant != 1 && variant != 2) {
         // rows that are not a multiple of 256 voxels: the flat mapping (every lane busy, summary kept)
@@ -700,8 +715,7 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
             if (v->claims_pending) {
                 const hipError_t qe = hipEventQuery(v->claims_done);
                 if (qe == hipSuccess) {
-                    const unsigned long long w = *v->h_claims;
-                    v->claim_fraction = v->claims_total > 0 ? (double)((w >> 32) + (w & 0xffffffffull)) / v->claims_total : 0.0;
+                    v->claim_fraction = claims_read_back(v);
                     v->claims_pending = false;
                     v->claims_known = true;
                 } else if (qe == hipErrorNotReady) {
@@ -718,23 +732,23 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
             // label launches classify only through bricks (a claimed wavefront-frame carries no label evidence either:
             // skipped = not observed, free space = outside the truncation band)
             if (label_ims && (mi.common.brick_q == 0 || v->variant == 11)) classify = false;
-            if (classify && v->variant != 8 && v->variant != 11 && v->variant != 12)
+            if (classify && v->variant != 8 && v->variant != 11 && v->variant != 12 && v->variant != 13)
                 classify = !v->claims_known || v->claim_fraction >= 0.10 || v->launches_unclassified >= 7;
             v->launches_unclassified = classify ? 0 : v->launches_unclassified + 1;
             const bool count_claims = classify && !v->claims_pending;
-            if (count_claims) {
-                if (!v->d_claims) {
-                    HIP_TRY(hipMalloc((void **)&v->d_claims, sizeof(unsigned long long)));
-                    HIP_TRY(hipHostMalloc((void **)&v->h_claims, sizeof(unsigned long long), hipHostMallocDefault));
-                    HIP_TRY(hipEventCreateWithFlags(&v->claims_done, hipEventDisableTiming));
-                }
-                mi.common.claim_counter = v->d_claims;   // cleared by the table kernel below (classify is true here)
+            if (classify && !v->d_claims) {
+                // the launch's counter block (tsdf_multiframe.hip.h, kListBuckets): per bucket the length of its brick sub-list and
+                // its share of the claims; cleared by the table kernel below.  Kernels with one claim counter use bucket 0's.
+                HIP_TRY(hipMalloc((void **)&v->d_claims, tsdfk::kCounterBytes + sizeof(tsdfk::ClassPoseTable)));   // + the frames' table
+                HIP_TRY(hipHostMalloc((void **)&v->h_claims, tsdfk::kCounterBytes, hipHostMallocDefault));
+                HIP_TRY(hipEventCreateWithFlags(&v->claims_done, hipEventDisableTiming));
             }
+            if (count_claims) mi.common.claim_counter = v->d_claims + 1;   // bucket 0's claims word
             if (classify) {
                 // depth tile tables of the n frames (two small launches), then the kernel that consults them
                 const size_t per_frame = tile_table_elems_host(mi.common.tiles_w, mi.common.tiles_h);
                 if (!v->d_tiles) HIP_TRY(hipMalloc((void **)&v->d_tiles, tsdfk::kMaxFramesPerLaunch * per_frame * sizeof(float2)));
-                int rc = build_tile_tables(v->stream, c, mi.common, depth_dev, masks_dev, n, v->d_tiles, count_claims ? v->d_claims : nullptr);
+                int rc = build_tile_tables(v->stream, c, mi.common, depth_dev, masks_dev, n, v->d_tiles, v->d_claims);
                 if (rc) return rc;
                 for (int f = 0; f < n; ++f) mi.frames[f].tiles = v->d_tiles + (size_t)f * per_frame;
                 for (int f = n; f < tsdfk::kMaxFramesPerLaunch; ++f) mi.frames[f] = mi.frames[0];
@@ -751,7 +765,52 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
             }
             mi.super_mask = nullptr;
             mi.nz_super = 1;
-            if (bricks && v->variant != 12) {   // variant 12: bricks without the super-brick pre-pass (A/B)
+            // the default: a pre-pass compacts the live bricks into a work list and the launch runs one wavefront per entry
+            // (variants 12 / 13: the first version for A/B -- a workgroup per four bricks of the whole slab, classified in its
+            // prologue, without / with the super-brick table)
+            const bool brick_list = bricks && v->variant != 12 && v->variant != 13;
+            if (brick_list) {
+                const int64_t per_group = (int64_t)mi.common.brick_groups * mi.common.bricks_per_group;
+                tsdfk::BrickListParams bl;
+                bl.nsx = (mi.common.bricks_per_group + tsdfk::kSuperBX - 1) / tsdfk::kSuperBX;
+                bl.nsy = (mi.common.brick_groups + tsdfk::kSuperBY - 1) / tsdfk::kSuperBY;
+                bl.nsz = (nz_groups + tsdfk::kSuperBZ - 1) / tsdfk::kSuperBZ;
+                const int64_t n_super = (int64_t)bl.nsx * bl.nsy * bl.nsz;
+                // a sub-list must hold every brick of every super-brick its hash deals to it: counted exactly, once per grid shape
+                if (v->work_nsuper != n_super) {
+                    std::vector<int64_t> per((size_t)tsdfk::kListBuckets, 0);
+                    for (int64_t id = 0; id < n_super; ++id) ++per[(size_t)(((uint32_t)id * 2654435761u) >> 26)];   // as classify_brick_list
+                    v->work_bucket_supers = *std::max_element(per.begin(), per.end());
+                    v->work_nsuper = n_super;
+                }
+                const int64_t cap = v->work_bucket_supers * tsdfk::kSuperBricks;
+                const int64_t total = cap * tsdfk::kListBuckets;
+                if (total > 0x7fffffffll - 4) return fail(TSDF_ERR_INVALID, "fused launch: %lld bricks exceed the work list's 32-bit index", (long long)total);
+                if (v->work_entries < (size_t)total) {
+                    if (v->d_work) HIP_TRY(hipFree(v->d_work));
+                    v->d_work = nullptr;
+                    v->work_entries = 0;
+                    HIP_TRY(hipMalloc((void **)&v->d_work, ((size_t)total + 4) * sizeof(uint4)));   // + the last, partial workgroup's reads
+                    v->work_entries = (size_t)total;
+                }
+                bl.list = v->d_work;
+                bl.counters = reinterpret_cast<unsigned char *>(v->d_claims);
+                bl.bucket_cap = (unsigned int)cap;
+                bl.poses = reinterpret_cast<tsdfk::ClassPoseTable *>(bl.counters + tsdfk::kCounterBytes);
+                hipLaunchKernelGGL(tsdfk::classify_brick_list, dim3((unsigned)((n_super + 3) / 4)), block, 0, v->stream, mi, bl);
+                const dim3 grid_list((unsigned)(((cap + 3) / 4 + 1) * tsdfk::kListBuckets));   // front groups + back groups of every sub-list
+                const uint4 *wl = v->d_work;
+                const unsigned char *wc = bl.counters;
+                if (label_ims)
+                    hipLaunchKernelGGL((tsdfk::integrate_brick_list<true, true, false>), grid_list, block, 0, v->stream, mi, wl, wc, bl.bucket_cap, (const tsdfk::ClassPoseTable *)bl.poses);
+                else if (any_mask)
+                    hipLaunchKernelGGL((tsdfk::integrate_brick_list<true, false, true>), grid_list, block, 0, v->stream, mi, wl, wc, bl.bucket_cap, (const tsdfk::ClassPoseTable *)bl.poses);
+                else
+                    hipLaunchKernelGGL((tsdfk::integrate_brick_list<true, false, false>), grid_list, block, 0, v->stream, mi, wl, wc, bl.bucket_cap, (const tsdfk::ClassPoseTable *)bl.poses);
+                grid_bricks = dim3((unsigned)per_group, 1, (unsigned)nz_groups);   // for the claim statistics: wavefront-frames = bricks x frames
+            }
+            else
+            if (bricks && v->variant != 12) {   // variant 13: the first version with its super-brick table (A/B)
                 const unsigned wgs = (unsigned)(((int64_t)mi.common.brick_groups * mi.common.bricks_per_group + 3) / 4);
                 mi.nz_super = (nz_groups + tsdfk::kSuperZ - 1) / tsdfk::kSuperZ;
                 const size_t words = (size_t)wgs * mi.nz_super;
@@ -765,7 +824,9 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
                 hipLaunchKernelGGL(tsdfk::classify_superbricks, dim3((unsigned)((words + 3) / 4)), block, 0, v->stream, mi, v->d_super, (int)wgs);
                 mi.super_mask = v->d_super;
             }
-            if (bricks && label_ims)
+            if (brick_list)
+                ;   // launched above
+            else if (bricks && label_ims)
                 hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, true, false, true, true>), grid_bricks, block, 0, v->stream, mi);
             else if (label_ims && v->flat)
                 hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, true, true, false>), grid_flat, block, 0, v->stream, mi);
@@ -794,8 +855,8 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
             if (count_claims) {
                 const dim3 &g = bricks ? grid_bricks : v->flat ? grid_flat : grid_rows;
                 // claims are counted per workgroup-frame, with bricks per wavefront-frame (four per workgroup)
-                v->claims_total = (double)g.x * g.y * g.z * n * (bricks ? 4.0 : 1.0);
-                HIP_TRY(hipMemcpyAsync(v->h_claims, v->d_claims, sizeof(unsigned long long), hipMemcpyDeviceToHost, v->stream));
+                v->claims_total = (double)g.x * g.y * g.z * n * ((bricks && !brick_list) ? 4.0 : 1.0);
+                HIP_TRY(hipMemcpyAsync(v->h_claims, v->d_claims, tsdfk::kCounterBytes, hipMemcpyDeviceToHost, v->stream));
                 HIP_TRY(hipEventRecord(v->claims_done, v->stream));
                 v->claims_pending = true;
             }
@@ -848,7 +909,7 @@ int frames_per_launch(const tsdf_volume *)
 
 bool can_fuse(const tsdf_volume *v)
 {
-    return (v->variant == 0 || (v->variant >= 4 && v->variant <= 12)) && v->cfg.dim_x % 4 == 0;
+    return (v->variant == 0 || (v->variant >= 4 && v->variant <= 13)) && v->cfg.dim_x % 4 == 0;
 }
 
 // A sequence of frames: fused frames_per_launch() at a time when the default kernel is selected.
@@ -1203,6 +1264,7 @@ int tsdf_destroy(tsdf_volume *v)
     if (v->d_flags) (void)hipFree(v->d_flags);
     if (v->d_tiles) (void)hipFree(v->d_tiles);
     if (v->d_super) (void)hipFree(v->d_super);
+    if (v->d_work) (void)hipFree(v->d_work);
     if (v->d_claims) (void)hipFree(v->d_claims);
     if (v->h_claims) (void)hipHostFree(v->h_claims);
     if (v->claims_done) (void)hipEventDestroy(v->claims_done);
@@ -1484,11 +1546,23 @@ int tsdf_shortcut_stats(tsdf_volume *v, int32_t enable, uint64_t counts_out[3])
         if (v->d_shortcut_stats) HIP_TRY(hipMemcpy(h, v->d_shortcut_stats, sizeof h, hipMemcpyDeviceToHost));
         for (int i = 0; i < 3; ++i) counts_out[i] = h[i];
     }
-    if (enable && !v->d_shortcut_stats) HIP_TRY(hipMalloc((void **)&v->d_shortcut_stats, 3 * sizeof(unsigned int)));
+    if (enable && !v->d_shortcut_stats) HIP_TRY(hipMalloc((void **)&v->d_shortcut_stats, 8 * sizeof(unsigned int)));
     if (v->d_shortcut_stats) {
-        if (enable) HIP_TRY(hipMemset(v->d_shortcut_stats, 0, 3 * sizeof(unsigned int)));
+        if (enable) HIP_TRY(hipMemset(v->d_shortcut_stats, 0, 8 * sizeof(unsigned int)));
         else { (void)hipFree(v->d_shortcut_stats); v->d_shortcut_stats = nullptr; }
     }
+    return TSDF_OK;
+}
+
+int tsdf_brick_list_stats(tsdf_volume *v, uint64_t counts_out[4])
+{
+    if (!v || !counts_out) return fail(TSDF_ERR_INVALID, "tsdf_brick_list_stats: NULL argument");
+    int rc = bind_device(v);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(v->stream));
+    unsigned int h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (v->d_shortcut_stats) HIP_TRY(hipMemcpy(h, v->d_shortcut_stats, sizeof h, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 4; ++i) counts_out[i] = h[3 + i];
     return TSDF_OK;
 }
 
@@ -1499,8 +1573,7 @@ int tsdf_classification_info(tsdf_volume *v, double info_out[2])
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(v->stream));
     if (v->claims_pending && hipEventQuery(v->claims_done) == hipSuccess) {
-        const unsigned long long w = *v->h_claims;
-        v->claim_fraction = v->claims_total > 0 ? (double)((w >> 32) + (w & 0xffffffffull)) / v->claims_total : 0.0;
+        v->claim_fraction = claims_read_back(v);
         v->claims_pending = false;
         v->claims_known = true;
     }
@@ -1512,7 +1585,7 @@ int tsdf_classification_info(tsdf_volume *v, double info_out[2])
 int32_t tsdf_frames_per_launch(const tsdf_volume *v)
 {
     if (!v) return 0;
-    const bool fuse = (v->variant == 0 || (v->variant >= 4 && v->variant <= 12)) && v->cfg.dim_x % 4 == 0;
+    const bool fuse = (v->variant == 0 || (v->variant >= 4 && v->variant <= 13)) && v->cfg.dim_x % 4 == 0;
     return fuse ? frames_per_launch(v) : 1;
 }
 
@@ -1552,7 +1625,7 @@ int tsdf_set_kernel_variant(tsdf_volume *v, int32_t variant)
     if (!v) return fail(TSDF_ERR_INVALID, "tsdf_set_kernel_variant: NULL handle");
     const int c = (variant - 32) & 15;
     const bool sum_ok = (variant >= 32 && variant < 112 && c < 12 && ((c >> 1) & 1)) || variant == 115 || variant == 119;
-    if (!(variant >= 0 && variant <= 12) && !(variant >= 16 && variant < 28) && !sum_ok)
+    if (!(variant >= 0 && variant <= 13) && !(variant >= 16 && variant < 28) && !sum_ok)
         return fail(TSDF_ERR_INVALID, "tsdf_set_kernel_variant: unknown variant %d", variant);
     v->variant = variant;
     return TSDF_OK;
@@ -2269,7 +2342,7 @@ int tsdf_batch_integrate_device(tsdf_batch *b, const float *depth_dev, const uin
     int64_t launch_voxels = 0;
     for (tsdf_volume *v : b->vols) launch_voxels += v->n_vox;
     // ... and not for many small volumes: one tile table per object has to be built per frame (64 x 100^3: 0.231 -> 0.262 ms)
-    const bool big_enough = b->vols[0]->variant == 8 || b->vols[0]->variant == 12 || launch_voxels >= (int64_t)n * 2000000;
+    const bool big_enough = b->vols[0]->variant == 8 || b->vols[0]->variant == 12 || b->vols[0]->variant == 13 || launch_voxels >= (int64_t)n * 2000000;
     const bool classify = any_mask && same_range && big_enough && classify_one_frame(b->vols[0], launch_voxels) &&
                           tiles_fit(b->h_params[s][0]);
     if (classify) {

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <new>
 #include <stdexcept>
 
 namespace {
@@ -85,28 +86,48 @@ void TSDF::Sync()
 	if ((grp_ ? tsdf_group_sync(grp_) : tsdf_sync(vol_)) != TSDF_OK) fail("tsdf_sync", __LINE__);
 }
 
-void TSDF::Download()
+int TSDF::download_mirrors()
 {
 	const long long n = voxels();
 	if (!voxel_grid_TSDF) voxel_grid_TSDF = new float[n > 0 ? n : 1];
 	if (!voxel_grid_weight) voxel_grid_weight = new float[n > 0 ? n : 1];
-	const int rc = grp_ ? tsdf_group_download(grp_, voxel_grid_TSDF, voxel_grid_weight)
-	                    : tsdf_download(vol_, voxel_grid_TSDF, voxel_grid_weight);
-	if (rc != TSDF_OK) fail("tsdf_download", __LINE__);
+	return grp_ ? tsdf_group_download(grp_, voxel_grid_TSDF, voxel_grid_weight)
+	            : tsdf_download(vol_, voxel_grid_TSDF, voxel_grid_weight);
+}
+
+void TSDF::Download()
+{
+	if (download_mirrors() != TSDF_OK) fail("tsdf_download", __LINE__);
+}
+
+// A destructor never throws: with ThrowOnError(true) a failure of the final download or of a file is reported on stderr and
+// the teardown goes on (an exception out of a destructor is std::terminate); by default it ends the program as every other
+// failure does (ref: src/tsdf.cu:405-420, checkCUDA inside the reference's destructor: print, reset, exit).
+void TSDF::fail_in_destructor(const char *what, int line) const
+{
+	if (!g_throw) fail(what, line);
+	std::cerr << "TSDF::~TSDF: " << what << " failed at LINE " << line << ": " << tsdf_last_error()
+	          << " (tsdf" << cfg_.id << ".ply / .bin may be missing or incomplete)" << std::endl;
 }
 
 TSDF::~TSDF()
 {
 	if (vol_ || grp_) {
 		if (save_on_destroy_) {
-			Download();  // ref: src/tsdf.cu:101-104
+			bool have = true;
+			try {
+				if (download_mirrors() != TSDF_OK) { have = false; fail_in_destructor("tsdf_download", __LINE__); }  // ref: src/tsdf.cu:101-104
+			} catch (const std::bad_alloc &) {   // the lazily allocated mirrors of a large grid
+				have = false;
+				std::cerr << "TSDF::~TSDF: out of host memory for the mirrors" << std::endl;
+			}
 			// ref: src/tsdf.cu:109-112 -- surface points, weight threshold 0.9 (tsdf_thresh 1.2 is unused there)
 			std::string name = "tsdf" + std::to_string(cfg_.id) + ".ply";
-			if ((grp_ ? tsdf_group_save_ply(grp_, name.c_str(), 0.9f) : tsdf_save_ply(vol_, name.c_str(), 0.9f)) != TSDF_OK)
-				fail("tsdf_save_ply", __LINE__);
+			if (have && (grp_ ? tsdf_group_save_ply(grp_, name.c_str(), 0.9f) : tsdf_save_ply(vol_, name.c_str(), 0.9f)) != TSDF_OK)
+				fail_in_destructor("tsdf_save_ply", __LINE__);
 			name = "tsdf" + std::to_string(cfg_.id) + ".bin";  // ref: src/tsdf.cu:116-132
-			if ((grp_ ? tsdf_group_save_bin(grp_, name.c_str()) : tsdf_save_bin(vol_, name.c_str())) != TSDF_OK)
-				fail("tsdf_save_bin", __LINE__);
+			if (have && (grp_ ? tsdf_group_save_bin(grp_, name.c_str()) : tsdf_save_bin(vol_, name.c_str())) != TSDF_OK)
+				fail_in_destructor("tsdf_save_bin", __LINE__);
 		}
 		if (grp_) tsdf_group_destroy(grp_);
 		if (vol_) tsdf_destroy(vol_);

@@ -70,7 +70,9 @@ struct IntegrateParams {
     float cz_margin;
     // Depth tile summaries (tsdf_multiframe.hip.h, classify_patch): tiles per image row / column, the half-width
     // in pixels by which a projected patch is widened (host: 1.5 + the projection's error bound), and optional
-    // counters {no claim, every voxel updated with dist = 1, no voxel updated} per wavefront-frame (null = off).
+    // counters {no claim, every voxel updated with dist = 1, no voxel updated} per wavefront-frame (null = off), followed by
+    // the brick work list's {super-bricks skipped by every frame, entries, entries left to classify themselves, of those:
+    // skipped by every frame} (tsdf_brick_list_stats).
     int tiles_w, tiles_h;
     float px_margin_u, px_margin_v;
     unsigned int *shortcut_stats;

@@ -46,6 +46,14 @@ struct FramePose {
 #define TSDF_TILE 16   /* pixels per tile edge: 16, or 8 for A/B builds (measured: the 4x larger tables cost more to build than their tighter ranges save -- 512^3 S-surf 0.0431 -> 0.0440 ms/frame, 16 x 200^3 masked 0.145 -> 0.277) */
 #endif
 constexpr int kTile = TSDF_TILE;
+
+// Counters of a classified fused launch, sharded: one word saturates at about 88 returning device-scope atomics per
+// microsecond (MI355X_MICROARCH.md, "dequeue"; measured here: one list head for the 262 144 super-bricks of a 1024^3 slab
+// made the pre-pass 1.7 ms instead of 0.13), so the brick work list is kListBuckets sub-lists with a head each, 256 bytes
+// apart: bucket b = {unsigned int front_entries, back_entries; unsigned long long claims; ...}.
+constexpr int kListBuckets = 64;
+constexpr int kBucketStride = 256;                          // bytes between buckets
+constexpr int kCounterBytes = kListBuckets * kBucketStride;
 static_assert(kTile == 8 || kTile == 16, "one wavefront per tile: 64 lanes x 1 or 4 pixels");
 
 // On top of the tiles a 2-D sparse table gives the same two quantities for ANY rectangle of tiles in four loads:
@@ -238,11 +246,12 @@ __global__ __launch_bounds__(256) void tile_sparse_table_scan(float2 *tables, in
 // from (i, j) at ty and at min(ty + 2^i, th - 1); the clamped partner lies inside the clipped range, and min / max are
 // idempotent, so every entry is the exact combination over its clipped block, as the scan version computes it.  One
 // workgroup per (x level j, frame): j + levels_y - 1 steps of two LDS reads per entry with a barrier each, instead of
-// 2^j + 2^i reads per entry.  zero_me (may be null): a word this launch clears for the kernel that follows it on the
-// stream (the fused launch's claim counter: saves a memset dispatch per launch).
+// 2^j + 2^i reads per entry.  zero_me (may be null): the launch's counter block (kCounterBytes: the sharded claim counters and
+// work-list lengths, see classify_brick_list), cleared here for the kernels that follow on the stream: saves a memset dispatch.
 __global__ __launch_bounds__(256) void tile_sparse_table(float2 *tables, int tw, int th, unsigned long long *zero_me)
 {
-    if (zero_me != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *zero_me = 0ull;
+    if (zero_me != nullptr && blockIdx.x == 0 && blockIdx.y == 0)
+        for (int k = threadIdx.x; k < kCounterBytes / 16; k += blockDim.x) reinterpret_cast<uint4 *>(zero_me)[k] = make_uint4(0u, 0u, 0u, 0u);
     const int lj = tile_levels(tw), li = tile_levels(th), n = tw * th;
     const int j = blockIdx.x;
     float2 *T = tables + (size_t)blockIdx.y * tile_table_elems(tw, th);
@@ -277,6 +286,48 @@ __global__ __launch_bounds__(256) void tile_sparse_table(float2 *tables, int tw,
     }
 }
 
+// What classify_patch reads of a frame: 16 dwords, grouped as four 16-byte words so that the 32 frames of a launch can be kept
+// structure-of-arrays (ClassPoseTable: lane f reads word k of frame f at w[k][f], 512 contiguous bytes per wave instruction
+// instead of 64 lanes picking 72-byte blocks apart).
+struct ClassPose {
+    float rx0, ry0, rz0, tx;
+    float rx1, ry1, rz1, ty;
+    float rx2, ry2, rz2, tz;
+    const float2 *tiles;
+    float cz_short, cz_pad;
+};
+static_assert(sizeof(ClassPose) == 64, "four 16-byte words");
+
+struct ClassPoseTable {
+    float4 w[4][kMaxFramesPerLaunch];
+};
+
+__device__ __forceinline__ ClassPose class_pose(const FramePose &q)
+{
+    ClassPose c;
+    c.rx0 = q.rx0; c.ry0 = q.ry0; c.rz0 = q.rz0; c.tx = q.tx;
+    c.rx1 = q.rx1; c.ry1 = q.ry1; c.rz1 = q.rz1; c.ty = q.ty;
+    c.rx2 = q.rx2; c.ry2 = q.ry2; c.rz2 = q.rz2; c.tz = q.tz;
+    c.tiles = q.tiles; c.cz_short = q.cz_short; c.cz_pad = q.cz_pad;
+    return c;
+}
+
+__device__ __forceinline__ ClassPose class_pose(const ClassPoseTable *__restrict__ t, const int f)
+{
+    union { ClassPose c; float4 w[4]; } u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) u.w[k] = t->w[k][f];
+    return u.c;
+}
+
+__device__ __forceinline__ void class_pose_store(ClassPoseTable *t, const int f, const ClassPose &c)
+{
+    union { ClassPose c; float4 w[4]; } u;
+    u.c = c;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t->w[k][f] = u.w[k];
+}
+
 // What one frame does to ALL voxels of a wavefront's patch -- the rectangle x in [xa, xb], y in [ya, yb] of slice
 // gz that contains them -- decided from the patch's corners and the depth tile tables, without projecting a
 // single voxel:
@@ -299,10 +350,9 @@ __global__ __launch_bounds__(256) void tile_sparse_table(float2 *tables, int tw,
 // projects the four corners of its slice and the six extremes are combined across the halves (min and max are exact,
 // so the class is the one the eight-corner evaluation gives).  Every lane of the wavefront must make the call.
 template <bool PAIRED = false>
-__device__ __forceinline__ int classify_patch(const IntegrateParams &p, const FramePose *__restrict__ qp, const int xa,
+__device__ __forceinline__ int classify_patch(const IntegrateParams &p, const ClassPose &q, const int xa,
                                               const int xb, const int ya, const int yb, const int gz, const int gz1 = -1)
 {
-    const FramePose q = *qp;      // this lane's frame
     if constexpr (!PAIRED) { if (q.tiles == nullptr) return 0; }
     const float dxa = (p.ox + (float)xa * p.vs) - q.tx, dxb = (p.ox + (float)xb * p.vs) - q.tx;
     const float dya = (p.oy + (float)ya * p.vs) - q.ty, dyb = (p.oy + (float)yb * p.vs) - q.ty;
@@ -388,7 +438,7 @@ __device__ __forceinline__ int classify_wg_patch(const IntegrateParams &p, const
         xb = min(xa + 255, p.dim_x - 1);
         yb = min(ya + rows_per_wg - 1, p.dim_y - 1);
     }
-    return classify_patch(p, pose, xa, xb, ya, yb, p.z_begin + lz);
+    return classify_patch(p, class_pose(*pose), xa, xb, ya, yb, p.z_begin + lz);
 }
 
 __global__ __launch_bounds__(256) void classify_workgroups(IntegrateParams p, FramePose pose, uint8_t *cls, int nbx, int nby,
@@ -427,7 +477,7 @@ __global__ __launch_bounds__(256) void classify_bricks(IntegrateParams p, FrameP
     if (g < p.brick_groups) {
         const int xa = i * p.brick_q * 4, ya = g * p.brick_r;
         const int z0 = lz * p.brick_s, z1 = min(z0 + p.brick_s - 1, p.nz - 1);
-        c = classify_patch(p, &pose, xa, xa + p.brick_q * 4 - 1, ya, min(ya + p.brick_r - 1, p.dim_y - 1), p.z_begin + z0,
+        c = classify_patch(p, class_pose(pose), xa, xa + p.brick_q * 4 - 1, ya, min(ya + p.brick_r - 1, p.dim_y - 1), p.z_begin + z0,
                            p.z_begin + z1);
     }
     cls[id] = (uint8_t)c;
@@ -452,7 +502,7 @@ __global__ __launch_bounds__(256) void classify_bricks_batched(const IntegratePa
     if (g < p.brick_groups) {
         const int xa = i * p.brick_q * 4, ya = g * p.brick_r;
         const int z0 = m.y * p.brick_s, z1 = min(z0 + p.brick_s - 1, p.nz - 1);
-        c = classify_patch(p, poses + m.x, xa, xa + p.brick_q * 4 - 1, ya, min(ya + p.brick_r - 1, p.dim_y - 1), p.z_begin + z0,
+        c = classify_patch(p, class_pose(poses[m.x]), xa, xa + p.brick_q * 4 - 1, ya, min(ya + p.brick_r - 1, p.dim_y - 1), p.z_begin + z0,
                            p.z_begin + z1);
     }
     cls[id] = (uint8_t)c;
@@ -509,8 +559,7 @@ constexpr int kSuperZ = 4;
 // lane per frame (classify_patch): all voxels updated with dist = 1, or none updated, without projecting any of them.
 // BRICK: a wavefront owns a compact brick of the slice -- brick_q quads of brick_r consecutive rows (IntegrateParams:
 // 64 x 4 voxels for 512-voxel rows, 40 x 6 for the reference's 200-voxel rows) -- instead of 256 consecutive voxels; b0 =
-// workgroup index within the slice, four consecutive bricks per workgroup, lane l owns quad (l % brick_q) of the brick's
-// row (l / brick_q).  A wave-instruction then touches brick_r row pieces of 16 * brick_q bytes instead of one 1-KiB piece
+// the wavefront's brick index within the slice group, lane l owns quad (l % brick_q) of the brick's row (l / brick_q).  A wave-instruction then touches brick_r row pieces of 16 * brick_q bytes instead of one 1-KiB piece
 // (the fused launches are bound by instruction issue, not by HBM), and the wavefront's voxels project onto a compact
 // pixel box, so a depth tile table can decide far more wavefront-frames without projecting a voxel: on S-surf an ideal
 // classifier claims 38 % of 256 x 1 rows but 77 % of 64 x 4 bricks (a row crosses both image borders and every
@@ -536,7 +585,7 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
         return (size_t)lzz * p.chunks_per_slice + (size_t)((gy * p.quads_per_row + quad) >> 6);
     };
     if constexpr (BRICK) {
-        const int brick = b0 * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.y);
+        const int brick = b0;   // BRICK: b0 is the wavefront's brick within the slice group (wave-uniform)
         const int g = brick / p.bricks_per_group, i = brick - g * p.bricks_per_group;
         // lane -> (slice, row, quad) of the brick: two divisions of a number below 64 by a divisor of at most 64, exact
         // as (x * ceil(2^16 / d)) >> 16 (the host's brick_per_magic / brick_q_magic)
@@ -986,7 +1035,7 @@ __global__ __launch_bounds__(256, R == 2 ? 6 : (BRICK ? (LABELS ? 6 : TSDF_BRICK
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 int cls = 0;
-                if (lane < mp.n_frames) cls = classify_patch(p, s_frames + lane, xa, xb, ya, yb, p.z_begin + wg_z);
+                if (lane < mp.n_frames) cls = classify_patch(p, class_pose(s_frames[lane]), xa, xb, ya, yb, p.z_begin + wg_z);
                 const unsigned long long fb = __ballot(cls == 1), sb = __ballot(cls == 2);
                 if (lane == 0) {
                     s_bits[0] = (unsigned int)fb;
@@ -1004,7 +1053,7 @@ __global__ __launch_bounds__(256, R == 2 ? 6 : (BRICK ? (LABELS ? 6 : TSDF_BRICK
             const int z0 = wg_z * p.brick_s, z1 = min(z0 + p.brick_s - 1, p.nz - 1);
             // frame = lane mod 32; the half-waves share the box's near and far slice (classify_patch<PAIRED>)
             static_assert(kMaxFramesPerLaunch == 32, "one frame per lane of a half-wave");
-            int cls = classify_patch<true>(p, s_frames + (lane & 31), xa, xa + p.brick_q * 4 - 1, ya,
+            int cls = classify_patch<true>(p, class_pose(s_frames[lane & 31]), xa, xa + p.brick_q * 4 - 1, ya,
                                            min(ya + p.brick_r - 1, p.dim_y - 1), p.z_begin + z0, p.z_begin + z1);
             if (g >= p.brick_groups || lane >= mp.n_frames) cls = 0;
             const unsigned long long fb = __ballot(cls == 1), sb = __ballot(cls == 2);
@@ -1028,8 +1077,9 @@ __global__ __launch_bounds__(256, R == 2 ? 6 : (BRICK ? (LABELS ? 6 : TSDF_BRICK
         free_frames = __builtin_amdgcn_readfirstlane(free_frames);
         skip_frames = __builtin_amdgcn_readfirstlane(skip_frames);
     }
-    multi_body<R, NT, FLAT, LABELS, MASKS, SHORT, BRICK>(mp.common, (const FramePose *)frames, mp.n_frames, wg_x, wg_y, wg_z,
-                                                         mp.labels, free_frames, skip_frames);
+    multi_body<R, NT, FLAT, LABELS, MASKS, SHORT, BRICK>(mp.common, (const FramePose *)frames, mp.n_frames,
+                                                         BRICK ? wg_x * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.y) : wg_x,
+                                                         wg_y, wg_z, mp.labels, free_frames, skip_frames);
 }
 
 // Ahead of a BRICK launch: which frames may do something to each super-brick -- the box of a workgroup's four bricks over
@@ -1061,9 +1111,164 @@ __global__ __launch_bounds__(256) void classify_superbricks(MultiParamsInline mp
     const int nz_groups = (p.nz + p.brick_s - 1) / p.brick_s;
     const int zg0 = zs * kSuperZ, zg1 = min(zg0 + kSuperZ - 1, nz_groups - 1);
     const int z0 = zg0 * p.brick_s, z1 = min((zg1 + 1) * p.brick_s - 1, p.nz - 1);
-    const int cls = classify_patch<true>(p, frames + (lane & 31), xa, xb, ya, yb, p.z_begin + z0, p.z_begin + z1);
+    const int cls = classify_patch<true>(p, class_pose(frames[lane & 31]), xa, xb, ya, yb, p.z_begin + z0, p.z_begin + z1);
     const unsigned long long work = __ballot(cls != 2 && lane < mp.n_frames);
     if (lane == 0) out[id] = (unsigned int)work;
+}
+
+// ---- live bricks only: a compacted work list -------------------------------------------------------------------------
+// Most wavefront bricks of a realistic launch are skipped by every one of its frames (behind the surfaces, outside the
+// views: 59 % on S-surf, more on a trajectory), and those that are not are concentrated in the surface band.  Dispatching
+// a workgroup per four bricks of the whole slab and letting the dead ones leave (the first version: classify_superbricks
+// + a classification in integrate_multi_inline's prologue) kept 5.4 of 8 wavefront slots per SIMD occupied, many of them by
+// wavefronts on their way out, and the dispatcher walked through long runs of dead workgroups while finished slots stayed
+// empty.  Now the Integrate launch only ever sees the bricks of super-bricks that some frame may touch:
+//   classify_brick_list   one WAVEFRONT per super-brick = kSuperBX x kSuperBY x kSuperBZ bricks (32 x 8 x 16 voxels with
+//                         the default 8 x 4 x 8-voxel brick), one frame per lane (paired half-waves: classify_patch<true>)
+//                         on the super-brick's box.  Skipped by every frame (45 % of S-surf's super-bricks): nothing is
+//                         emitted.  Otherwise its bricks are appended to the work list -- ONE atomic per wavefront, sixteen
+//                         16-byte entries from sixteen lanes -- with what the box proved for each frame (a claim for the box
+//                         holds for every brick inside it) and a flag when some frame is left undecided.
+//   integrate_brick_list  one wavefront per list entry {brick, slice group, free frames, skipped frames}: no LDS, no barrier,
+//                         no workgroup-wide prologue.  A brick whose super-brick left frames undecided classifies itself
+//                         first (one frame per lane, as before -- in the shadow of the other wavefronts' per-voxel work) and
+//                         leaves if every frame skips it.  The grid is sized for the worst case; the workgroups past the end
+//                         of the sub-lists -- all at the END of the dispatch order -- leave on one scalar load.
+// Same claims, same per-voxel code, same bits (every classified parity test runs through it).  Measured (rocprofv3, same
+// box): the Integrate kernel of a 32-frame launch 1.132 -> 0.93 ms on S-surf 512^3, 5.89 -> 4.84 ms on the fr3 trajectory
+// at 1024^3.  (A pre-pass that also classified every brick -- so that no wavefront would ever be launched to leave -- cost
+// more than that saves: 0.20 ms and 2.1 ms per launch, sixteen dependent classifications per wavefront.)
+// bricks per super-brick along x, y (row groups), z (slice groups).  Four along x: a workgroup of integrate_brick_list takes
+// four consecutive entries of a sub-list -- the four x-neighbours of one row group and slice group, whose row pieces (32 bytes
+// each with the default 8 x 4 x 8-voxel brick) make up whole 128-byte lines.  (2 x 4 x 2, the more compact box, left every
+// workgroup with half lines: the all-free-space launch 0.72 -> 0.90 ms.)
+constexpr int kSuperBX = 4, kSuperBY = 2, kSuperBZ = 2;
+constexpr int kSuperBricks = kSuperBX * kSuperBY * kSuperBZ;
+static_assert(kSuperBricks <= 32, "one lane of a half-wave per brick of the super-brick");
+constexpr unsigned int kBrickUndecided = 0x80000000u;     // list entry flag: the brick has to classify itself
+
+struct BrickListParams {
+    uint4 *list;               // kListBuckets sub-lists of bucket_cap entries: a super-brick's bricks go to the sub-list its index hashes to
+    unsigned char *counters;   // the launch's counter block (kCounterBytes), zeroed ahead of the pre-pass (tile_sparse_table)
+    unsigned int bucket_cap;   // entries per sub-list: every brick of every super-brick it can receive
+    ClassPoseTable *poses;     // the launch's frames for classify_patch, structure-of-arrays (written by the pre-pass)
+    int nsx, nsy, nsz;         // super-bricks along x, y, z
+};
+
+__global__ __launch_bounds__(256) void classify_brick_list(MultiParamsInline mp, BrickListParams bl)
+{
+    typedef const char __attribute__((address_space(4))) *kernarg_ptr;
+    kernarg_ptr base = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    const FramePose *frames = (const FramePose *)(base + offsetof(MultiParamsInline, frames));
+    const IntegrateParams &p = mp.common;
+    const int id = (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.y), lane = threadIdx.x;
+    if (id >= bl.nsx * bl.nsy * bl.nsz) return;
+    // slice groups fastest, then x, then y: neighbours in the list are neighbours in the volume (and in the depth frames)
+    const int sz = id % bl.nsz, t = id / bl.nsz, sx = t % bl.nsx, sy = t / bl.nsx;
+    const int nzg = (p.nz + p.brick_s - 1) / p.brick_s;
+    const int i0 = sx * kSuperBX, g0 = sy * kSuperBY, zg0 = sz * kSuperBZ;
+    const int i1 = min(i0 + kSuperBX, p.bricks_per_group) - 1, g1 = min(g0 + kSuperBY, p.brick_groups) - 1, zg1 = min(zg0 + kSuperBZ, nzg) - 1;
+    const unsigned int frames_mask = mp.n_frames >= 32 ? 0xffffffffu : ((1u << mp.n_frames) - 1u);
+    static_assert(kMaxFramesPerLaunch == 32, "one frame per lane of a half-wave");
+    const int xa = i0 * p.brick_q * 4, xb = (i1 + 1) * p.brick_q * 4 - 1;
+    const int ya = g0 * p.brick_r, yb = min((g1 + 1) * p.brick_r, p.dim_y) - 1;
+    const int z0 = zg0 * p.brick_s, z1 = min((zg1 + 1) * p.brick_s, p.nz) - 1;
+    const ClassPose mine_q = class_pose(frames[lane & 31]);
+    // the frames as integrate_brick_list's self-classifying wavefronts read them (the first wavefront of the launch writes)
+    if (id == 0 && lane < kMaxFramesPerLaunch) class_pose_store(bl.poses, lane, mine_q);
+    const int cls = classify_patch<true>(p, mine_q, xa, xb, ya, yb, p.z_begin + z0, p.z_begin + z1);
+    const unsigned int super_free = (unsigned int)__ballot(cls == 1) & frames_mask;
+    const unsigned int super_skip = (unsigned int)__ballot(cls == 2) & frames_mask;
+    const int n_in = (i1 - i0 + 1) * (g1 - g0 + 1) * (zg1 - zg0 + 1);
+    // the sub-list of this super-brick: a multiplicative hash of its index, so that every sub-list samples the whole volume
+    // (index mod 64 would be the slice group -- the sub-lists of slice groups in free space or behind the walls would run dry
+    // long before the others and the launch would end on a quarter of its wavefronts)
+    static_assert(kListBuckets == 64, "the hash keeps the top six bits");
+    const unsigned int bkt = ((unsigned int)id * 2654435761u) >> 26;
+    unsigned char *bucket = bl.counters + (size_t)bkt * kBucketStride;
+    if (lane == 0) {
+        // claims at super-brick granularity (what the per-launch decision is made from; the host adds the buckets up); the
+        // diagnostic counters are exact: a super-brick skipped by every frame settles its bricks' wavefront-frames here, all
+        // others are counted by the wavefronts of integrate_brick_list
+        if (p.claim_counter != nullptr && (super_free | super_skip) != 0u)
+            atomicAdd(reinterpret_cast<unsigned long long *>(bucket + 8),
+                      ((unsigned long long)(n_in * __popc(super_free)) << 32) | (unsigned long long)(n_in * __popc(super_skip)));
+        if (p.shortcut_stats != nullptr) {
+            if (super_skip == frames_mask) { atomicAdd(p.shortcut_stats + 2, (unsigned)(n_in * mp.n_frames)); atomicAdd(p.shortcut_stats + 3, 1u); }
+            else {
+                atomicAdd(p.shortcut_stats + 4, (unsigned)n_in);
+                if ((super_free | super_skip) != frames_mask) atomicAdd(p.shortcut_stats + 5, (unsigned)n_in);
+            }
+        }
+    }
+    if (super_skip == frames_mask) return;    // nothing in here sees anything
+    const int k = lane;                       // lane k < kSuperBricks: brick k of the super-brick
+    const int i = i0 + k % kSuperBX, g = g0 + (k / kSuperBX) % kSuperBY, zg = zg0 + k / (kSuperBX * kSuperBY);
+    const bool mine = k < kSuperBricks && i <= i1 && g <= g1 && zg <= zg1;
+    const unsigned long long live_mask = __ballot(mine);
+    // Heavy work first: the bricks of a super-brick with undecided frames (they classify themselves and may take the
+    // per-voxel path) grow the sub-list from its front, the bricks whose every frame is decided (a few weight additions
+    // each) from its back; integrate_brick_list walks the front first.  A launch of few wavefronts per slot (a 200^3
+    // volume: four) ends when its last long wavefront does, so the long ones must not start last.
+    const unsigned int undecided = (super_free | super_skip) != frames_mask ? kBrickUndecided : 0u;
+    const unsigned int n_live = (unsigned)__popcll(live_mask);
+    unsigned int at = 0u;
+    if (lane == 0) at = atomicAdd(reinterpret_cast<unsigned int *>(bucket) + (undecided ? 0 : 1), n_live);
+    at = __builtin_amdgcn_readfirstlane(at);
+    at = bkt * bl.bucket_cap + (undecided ? at : bl.bucket_cap - at - n_live);
+    if (mine)
+        bl.list[at + (unsigned)__popcll(live_mask & ((1ull << lane) - 1ull))] =
+            make_uint4((unsigned)(g * p.bricks_per_group + i) | undecided, (unsigned)zg, super_free, super_skip);
+}
+
+template <bool NT, bool LABELS, bool MASKS>
+__global__ __launch_bounds__(256, LABELS ? 6 : TSDF_BRICK_WAVES) void integrate_brick_list(MultiParamsInline mp, const uint4 *__restrict__ list,
+                                                                                          const unsigned char *__restrict__ counters,
+                                                                                          const unsigned int bucket_cap,
+                                                                                          const ClassPoseTable *__restrict__ poses)
+{
+    typedef const char __attribute__((address_space(4))) *kernarg_ptr;
+    kernarg_ptr base = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    const FramePose *frames = (const FramePose *)(base + offsetof(MultiParamsInline, frames));
+    // workgroup j takes group j / kListBuckets of sub-list j % kListBuckets -- four consecutive entries, one per wavefront (four
+    // x-neighbours, see kSuperBX) -- first the groups of the front part (bricks with undecided frames), then those of the back
+    // part, walking down from the end; the sub-lists run dry together, at the end of the dispatch order
+    const unsigned int b = blockIdx.x % kListBuckets, grp = blockIdx.x / kListBuckets;
+    const unsigned int wave = (unsigned)__builtin_amdgcn_readfirstlane((int)threadIdx.y);
+    const uint2 n = *reinterpret_cast<const uint2 *>(counters + (size_t)b * kBucketStride);   // {front, back} entries (scalar load)
+    const unsigned int front_groups = (n.x + 3u) / 4u;
+    unsigned int at;
+    if (grp < front_groups) {
+        at = grp * 4u + wave;
+        if (at >= n.x) return;
+    } else {
+        const unsigned int k = (grp - front_groups) * 4u + wave;
+        if (k >= n.y) return;
+        at = bucket_cap - 1u - k;
+    }
+    const uint4 e = list[(size_t)b * bucket_cap + at];
+    const int brick = (int)(e.x & ~kBrickUndecided), zg = (int)e.y;
+    unsigned int free_frames = e.z, skip_frames = e.w;
+    if (e.x & kBrickUndecided) {
+        // the super-brick's box left frames undecided: the brick's own, smaller box may decide them
+        const IntegrateParams &p = mp.common;
+        const int lane = threadIdx.x;
+        const unsigned int frames_mask = mp.n_frames >= 32 ? 0xffffffffu : ((1u << mp.n_frames) - 1u);
+        const int g = brick / p.bricks_per_group, i = brick - g * p.bricks_per_group;
+        const int xa = i * p.brick_q * 4, ya = g * p.brick_r;
+        const int z0 = zg * p.brick_s, z1 = min(z0 + p.brick_s - 1, p.nz - 1);
+        const int cls = classify_patch<true>(p, class_pose(poses, lane & 31), xa, xa + p.brick_q * 4 - 1, ya, min(ya + p.brick_r - 1, p.dim_y - 1),
+                                             p.z_begin + z0, p.z_begin + z1);
+        free_frames |= (unsigned int)__ballot(cls == 1) & frames_mask;
+        skip_frames |= (unsigned int)__ballot(cls == 2) & frames_mask;
+        free_frames = __builtin_amdgcn_readfirstlane(free_frames);
+        skip_frames = __builtin_amdgcn_readfirstlane(skip_frames);
+        if (skip_frames == frames_mask) {         // every frame skips the brick
+            if (p.shortcut_stats != nullptr && lane == 0) { atomicAdd(p.shortcut_stats + 2, (unsigned)mp.n_frames); atomicAdd(p.shortcut_stats + 6, 1u); }
+            return;
+        }
+    }
+    multi_body<1, NT, false, LABELS, MASKS, true, true>(mp.common, frames, mp.n_frames, brick, 0, zg, mp.labels, free_frames, skip_frames);
 }
 
 // Experiment (variant 5): XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs, so
@@ -1130,7 +1335,8 @@ __global__ __launch_bounds__(256, 8) void integrate_single_bricks(IntegrateParam
 {
     const unsigned c = p.wg_class[(blockIdx.x + gridDim.x * blockIdx.z) * 4u + threadIdx.y];   // wave-uniform
     if (c == 2u) return;
-    multi_body<1, NT, false, false, true, true, true>(p, &pose, 1, blockIdx.x, 0, blockIdx.z, LabelState(), c == 1u ? 1u : 0u, 0u);
+    multi_body<1, NT, false, false, true, true, true>(p, &pose, 1, (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.y), 0,
+                                                      blockIdx.z, LabelState(), c == 1u ? 1u : 0u, 0u);
 }
 
 // The batched launch over bricks with a class per wavefront (classify_bricks_batched): per-object volumes are fed
@@ -1146,7 +1352,8 @@ __global__ __launch_bounds__(256, 8) void integrate_multi_batched_bricks(const I
     if (c == 2u) return;
     const int2 m = group_map[blockIdx.z];
     const IntegrateParams p = params[m.x];
-    multi_body<1, NT, false, false, true, true, true>(p, poses + m.x, 1, blockIdx.x, 0, m.y, LabelState(), c == 1u ? 1u : 0u, 0u);
+    multi_body<1, NT, false, false, true, true, true>(p, poses + m.x, 1, (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.y), 0,
+                                                      m.y, LabelState(), c == 1u ? 1u : 0u, 0u);
 }
 
 // The instance masks of one frame for up to kGatherMasks objects, copied into a batch's frame pool by ONE launch

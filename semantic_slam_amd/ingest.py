@@ -53,3 +53,44 @@ def load_associations(path):
             if len(p) >= 4:
                 out.append((p[0], p[1], p[3]))
     return out
+
+
+def load_depth_png(path):
+    """The 16-bit depth PNG of one TUM RGB-D frame as uint16 [H, W] -- the payload `tsdf_integrate_u16` takes (metres =
+    value / 5000, ref: config/TUM3.yaml:34; the labeller reads the file unchanged, ref:
+    examples/label_instance_rgbd.cpp:141-152 `cv::imread(..., CV_LOAD_IMAGE_UNCHANGED)`).  Read with Pillow (OpenCV is
+    not in this image); an 8-bit or colour file is refused rather than silently rescaled."""
+    from PIL import Image
+    with Image.open(path) as im:
+        if im.mode not in ("I;16", "I;16L", "I;16B", "I"):
+            raise ValueError(f"{path}: expected a 16-bit single-channel depth image, got mode {im.mode!r}")
+        a = np.array(im)
+    if a.ndim != 2:
+        raise ValueError(f"{path}: expected one channel, got shape {a.shape}")
+    if a.dtype != np.uint16:
+        if a.min() < 0 or a.max() > 65535:
+            raise ValueError(f"{path}: values outside the 16-bit range")
+        a = a.astype(np.uint16)
+    return np.ascontiguousarray(a)
+
+
+def save_depth_png(path, raw_u16):
+    """Write a uint16 [H, W] frame as a 16-bit greyscale PNG (what the TUM dataset ships; used by tests and tools)."""
+    from PIL import Image
+    a = np.ascontiguousarray(raw_u16, dtype=np.uint16)
+    Image.fromarray(a).save(path, format="PNG")
+
+
+def iter_keyframes(bundle_path, associations_path, root):
+    """The offline labeller's keyframe loop (ref: examples/label_instance_rgbd.cpp:78-110) as far as the TSDF needs it:
+    yields (Twc [16] float32, raw depth uint16 [H, W], depth file name) per keyframe, poses from bundle.txt
+    (Twc = inverse of the stored Tcw, as KeyFrame::GetPoseInverse), images named by associations.txt below `root`
+    (the TUM sequence directory).  Feed to `tsdf_integrate_u16(raw, 5000, 4, 3, Twc)` for the labeller's own depth
+    preparation (every 4th row / 3rd column, / 5000; ref: :89-100), or with steps (1, 1) for the whole frame."""
+    import os
+    Twc = pose_inverse(load_bundle_poses(bundle_path))
+    names = load_associations(associations_path)
+    if len(names) != len(Twc):
+        raise ValueError(f"{bundle_path} holds {len(Twc)} keyframes, {associations_path} names {len(names)}")
+    for T, (_, _rgb, depth_name) in zip(Twc, names):
+        yield T.ravel().copy(), load_depth_png(os.path.join(root, depth_name)), depth_name

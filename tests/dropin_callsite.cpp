@@ -9,13 +9,17 @@
 //                        n x { float cam2world[16], float depth[480*640] }.
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "tsdf.hpp"
 
 int main(int argc, char **argv)
 {
-	if (argc < 2) { std::fprintf(stderr, "usage: %s frames.bin\n", argv[0]); return 2; }
+	if (argc < 2) { std::fprintf(stderr, "usage: %s frames.bin [--throw]\n", argv[0]); return 2; }
+	// --throw: the opt-in exception mode; the destructor must report a failed file on stderr and return normally
+	// (tests/test_gpu_dropin.py runs this in a directory it cannot write to)
+	if (argc > 2 && std::string(argv[2]) == "--throw") TSDF::ThrowOnError(true);
 	FILE *fp = std::fopen(argv[1], "rb");
 	if (!fp) { std::perror(argv[1]); return 2; }
 	int id = 0, n = 0;
@@ -42,5 +46,6 @@ int main(int argc, char **argv)
 	// public mirrors exist from construction on, as in the reference (ref: include/tsdf.hpp:40-43)
 	if (!tsdf->voxel_grid_TSDF || !tsdf->voxel_grid_weight) return 3;
 	delete (tsdf);
+	std::puts("destructor returned");
 	return 0;
 }

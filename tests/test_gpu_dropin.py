@@ -70,6 +70,36 @@ def test_object_callsite_sequence(cuda, oracle, tmp_path):
     assert (tmp_path / f"tsdf{vol_id}.ply").read_bytes() == (tmp_path / "want.ply").read_bytes()
 
 
+def test_destructor_reports_a_failed_file_and_never_throws(cuda, tmp_path):
+    """TSDF::ThrowOnError(true) turns failures into exceptions -- except in the destructor, where an exception would be
+    std::terminate: there a file that cannot be written is reported on stderr and the teardown goes on.  The harness runs
+    in a directory it may not write to; it must print "destructor returned" and exit 0.  (Default mode keeps the
+    reference's print-and-exit, ref: src/tsdf.cu:405-420.)"""
+    exe = build_harness(tmp_path)
+    inp = tmp_path / "frames.bin"
+    with open(inp, "wb") as f:
+        f.write(struct.pack("<ii", 3, 1))
+        f.write(synth.identity_pose().tobytes())
+        f.write(np.array([-0.4, -0.4, 0.7], np.float32).tobytes())
+        f.write(synth.identity_pose().tobytes())
+        f.write(np.full((480, 640), 1.0, np.float32).tobytes())
+    locked = tmp_path / "locked"
+    locked.mkdir()
+    os.chmod(locked, 0o555)
+    try:
+        if os.access(str(locked), os.W_OK):
+            pytest.skip("running as a user who may write anywhere (root): cannot provoke the failure")
+        p = subprocess.run([exe, str(inp), "--throw"], cwd=str(locked), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert p.returncode == 0, p.stderr
+        assert "destructor returned" in p.stdout
+        assert "TSDF::~TSDF" in p.stderr and "tsdf_save_ply" in p.stderr
+        # default mode: the reference's behaviour -- print and exit(EXIT_FAILURE)
+        p = subprocess.run([exe, str(inp)], cwd=str(locked), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert p.returncode == 1 and "FatalError" in p.stderr and "destructor returned" not in p.stdout
+    finally:
+        os.chmod(locked, 0o755)
+
+
 @pytest.mark.parametrize("surface", ["pointers", "cv_mat"])
 def test_tsdffusion_native_backend(cuda, oracle, tmp_path, surface):
     """class TSDFfusion over the native library: the volume of the reference's Python glue

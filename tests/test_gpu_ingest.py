@@ -35,6 +35,46 @@ def test_u16_depth_on_device_equals_host_preparation(cuda, oracle, steps):
     assert np.array_equal(w, ref_w) and np.array_equal(t.view(np.uint32), ref_t.view(np.uint32))
 
 
+def test_keyframes_from_png_files_through_the_u16_path(cuda, oracle, tmp_path):
+    """N4 end to end: bundle.txt + associations.txt + 16-bit depth PNGs on disk -> ingest.iter_keyframes ->
+    tsdf_integrate_u16 with the labeller's preparation (factor 5000, every 4th row / 3rd column; ref:
+    examples/label_instance_rgbd.cpp:89-100) == the oracle fed oracle.depth_prep of the same raw frames."""
+    z = np.load(GOLD, allow_pickle=False)
+    n = 5
+    names = [str(x) for x in z["depth_names"][:n]]
+    root = tmp_path / "seq"
+    (root / "depth").mkdir(parents=True)
+    dims, vs = (128, 96, 64), 0.02
+    origin = np.array([-1.28, -0.96, 0.7], np.float32)
+    Twc = ingest.pose_inverse(z["Tcw"][:n])
+    base = Twc[0].ravel()
+    scene = synth.SurfScene(dims, vs, origin)
+    for k, name in enumerate(names):
+        raw = np.round(np.clip(scene.depth(oracle.cam2base(base, Twc[k].ravel())), 0, 13.0) * 5000.0).astype(np.uint16)
+        ingest.save_depth_png(str(root / name), raw)
+    with open(tmp_path / "bundle.txt", "w") as f:
+        f.write(f"{n} 0\n")
+        for T in z["Tcw"][:n]:
+            f.write("0 0 0\n")
+            for r in range(3):
+                f.write(" ".join(f"{T[r, c]:.9g}" for c in range(3)) + "\n")
+            f.write(" ".join(f"{T[r, 3]:.9g}" for r in range(3)) + "\n")
+    with open(tmp_path / "associations.txt", "w") as f:
+        for name in names:
+            ts = name.split("/")[1][:-4]
+            f.write(f"{ts} rgb/{ts}.png {ts} {name}\n")
+    cfg = capi.make_config(dims, vs, origin, base2world=base)
+    ref_t, ref_w = oracle.init_grid(dims)
+    with capi.Volume(cfg) as vol:
+        for pose, raw, _ in ingest.iter_keyframes(str(tmp_path / "bundle.txt"), str(tmp_path / "associations.txt"), str(root)):
+            vol.integrate_u16(raw, pose, 5000.0, 4, 3)
+            oracle.integrate(cfg.cam_K, oracle.cam2base(base, pose), oracle.depth_prep(raw, 5000.0), dims, origin, vs, cfg.trunc_margin,
+                             ref_t, ref_w)
+        t, w = vol.download()
+    assert ref_w.sum() > 1000
+    assert np.array_equal(w, ref_w) and np.array_equal(t.view(np.uint32), ref_t.view(np.uint32))
+
+
 def test_config2_1024_cube_on_the_fr3_trajectory(cuda, oracle):
     """BASELINE configs[2]: 1024^3 @ 2 mm on one MI355X (8.6 GB resident), camera poses = keyframes of
     the reference's saved fr3_office run (base = first keyframe), depth rendered per pose with TUM

@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("dims", [(256, 42, 30), (200, 42, 30), (36, 20, 12)])   # row mapping, flat, flat + partial chunk
-@pytest.mark.parametrize("variant", [0, 4, 3, 5, 8, 9, 10, 11, 12])   # 9: memory-order dispatch; 10: slices fastest without the rotation; 12: bricks without the super-brick pre-pass; 11: rows classified per workgroup (default: bricks per wavefront)
+@pytest.mark.parametrize("variant", [0, 4, 3, 5, 8, 9, 10, 11, 12, 13])   # 9: memory-order dispatch; 10: slices fastest without the rotation; 12: bricks without the super-brick pre-pass; 11: rows classified per workgroup (default: bricks per wavefront)
 @pytest.mark.parametrize("n_frames", [1, 3, 4, 9, 32, 33, 70])   # kMaxFramesPerLaunch = 32: one full pass, +1, 2 full + 6
 def test_fused_frames_equal_sequential_and_oracle(cuda, oracle, n_frames, variant, dims):
     if n_frames > 9 and (variant != 0 or dims[0] == 36):

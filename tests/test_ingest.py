@@ -66,3 +66,55 @@ def test_config0_cpu_plumbing(oracle):
     n = oracle.integrate(synth.TUM_K, cam2base, masked, dims, origin, vs, 0.05, t, w)
     assert n > 10000 and w.max() == 1.0
     assert np.count_nonzero(t < 1.0) > 1000 and t.min() >= -1.0 and t.max() <= 1.0
+
+
+def test_depth_png_roundtrip_and_keyframe_iteration(tmp_path, oracle):
+    """N4: 16-bit depth PNGs named as the reference's result/rgbd/associations.txt names them, poses in a bundle.txt of
+    the reference's layout; iter_keyframes hands back (Twc, raw uint16) per keyframe -- the arguments of
+    tsdf_integrate_u16 -- bit for bit, and the labeller's preparation of the raw frame (ref:
+    examples/label_instance_rgbd.cpp:89-100) gives the oracle's depth_prep."""
+    rng = np.random.default_rng(3)
+    z = np.load(GOLD, allow_pickle=False)
+    n = 4
+    names = [str(x) for x in z["depth_names"][:n]]
+    root = tmp_path / "rgbd_dataset_freiburg3_long_office_household"
+    (root / "depth").mkdir(parents=True)
+    scene = synth.SurfScene((256, 256, 256), 0.01, np.array([-1.28, -1.28, 0.8], np.float32))
+    raws = []
+    for k, name in enumerate(names):
+        raw = np.round(np.clip(scene.depth(scene.pose(k, 8)), 0, 13.0) * 5000.0).astype(np.uint16)
+        raw[rng.integers(0, 480, 50), rng.integers(0, 640, 50)] = rng.integers(0, 65536, 50).astype(np.uint16)   # the full range survives
+        raw[0, 0], raw[479, 639] = 65535, 1
+        ingest.save_depth_png(str(root / name), raw)
+        raws.append(raw)
+    with open(tmp_path / "bundle.txt", "w") as f:
+        f.write(f"{n} 0\n")
+        for T in z["Tcw"][:n]:
+            f.write("0 0 0\n")
+            for r in range(3):
+                f.write(" ".join(f"{T[r, c]:.9g}" for c in range(3)) + "\n")
+            f.write(" ".join(f"{T[r, 3]:.9g}" for r in range(3)) + "\n")
+    with open(tmp_path / "associations.txt", "w") as f:
+        for name in names:
+            ts = name.split("/")[1][:-4]
+            f.write(f"{ts} rgb/{ts}.png {ts} {name}\n")
+    got = list(ingest.iter_keyframes(str(tmp_path / "bundle.txt"), str(tmp_path / "associations.txt"), str(root)))
+    assert len(got) == n
+    want_Twc = ingest.pose_inverse(z["Tcw"][:n])
+    for (Twc, raw, name), want_raw, want_T, want_name in zip(got, raws, want_Twc, names):
+        assert name == want_name and raw.dtype == np.uint16 and raw.shape == (480, 640)
+        assert np.array_equal(raw, want_raw)
+        assert np.array_equal(Twc, want_T.ravel())
+        d = oracle.depth_prep(raw, 5000.0)
+        assert d[0, 0] == np.float32(65535) * (np.float32(1.0) / np.float32(5000.0)) and d[1, 0] == 0.0 and d[0, 1] == 0.0
+    # an 8-bit image is refused, not rescaled
+    from PIL import Image
+    Image.fromarray(np.zeros((480, 640), np.uint8)).save(str(tmp_path / "eight.png"))
+    import pytest
+    with pytest.raises(ValueError, match="16-bit"):
+        ingest.load_depth_png(str(tmp_path / "eight.png"))
+    # more poses than names is an error, not a truncation
+    with open(tmp_path / "short.txt", "w") as f:
+        f.write("1.0 rgb/1.0.png 1.0 depth/1.0.png\n")
+    with pytest.raises(ValueError, match="keyframes"):
+        list(ingest.iter_keyframes(str(tmp_path / "bundle.txt"), str(tmp_path / "short.txt"), str(root)))

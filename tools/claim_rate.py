@@ -39,6 +39,7 @@ for shape in a.shapes.split(":"):
         vol.integrate_frames_device(ptrs, poses)      # steady state: second pass counted
         vol.shortcut_stats(True)
         vol.integrate_frames_device(ptrs, poses)
+        bl = vol.brick_list_stats()
         pv, fr, sk = vol.shortcut_stats(False)
         tot = pv + fr + sk
         vol.sync()
@@ -48,4 +49,6 @@ for shape in a.shapes.split(":"):
         vol.sync()
         ms = (time.perf_counter() - t0) / (3 * n) * 1e3
         print(f"  brick {shape:8s}: per-voxel {pv / tot:.4f}  free {fr / tot:.4f}  skipped {sk / tot:.4f}  "
-              f"({tot} wavefront-frames)  {ms:.4f} ms/frame", flush=True)
+              f"({tot} wavefront-frames)  {ms:.4f} ms/frame\n"
+              f"      work list over {n // 32} launches: super-bricks every frame skipped {bl[0]}, bricks listed {bl[1]}, of those left to "
+              f"classify themselves {bl[2]}, of those skipped after all {bl[3]}", flush=True)

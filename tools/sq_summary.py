@@ -12,7 +12,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 acc, kernel = {}, None
 for part in "ab":
     f = glob.glob(os.path.join(root, "gpurun_out", f"sq_{tag}_{part}", "**", "*counter_collection.csv"), recursive=True)[0]
-    rows = [r for r in csv.DictReader(open(f)) if "integrate_multi_inline<" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(f)) if "integrate_multi_inline<" in r["Kernel_Name"] or "integrate_brick_list<" in r["Kernel_Name"]]
     # the dominant instantiation (most dispatches), full-size launches only (the largest grid)
     names = {}
     for r in rows:
