@@ -40,6 +40,23 @@ class TsdfError(RuntimeError):
     pass
 
 
+# kernel variants of the library as shipped (tsdf_set_kernel_variant; csrc/tsdf_capi.hip); every other number exists only in
+# the measurement build (`make -C semantic_slam_amd/csrc experiments`, loaded through TSDF_HIP_LIB)
+SHIPPED_VARIANTS = (0, 1, 3, 7, 8)
+
+
+def experiments_build():
+    """True when the loaded library is the measurement build (-DTSDF_EXPERIMENTS)."""
+    return b"+experiments" in load().tsdf_version()
+
+
+def variants(*wanted):
+    """Those of `wanted` the loaded library knows: the shipped ones, and the experiments when that build is loaded (tests
+    parametrise over this, so the product's test matrix is exactly what ships)."""
+    exp = experiments_build()
+    return [v for v in wanted if v in SHIPPED_VARIANTS or exp]
+
+
 class TsdfConfig(C.Structure):
     """Mirror of `struct tsdf_config` (include/tsdf_hip.h)."""
     _fields_ = [

@@ -29,6 +29,9 @@
 #include "tsdf_labels.hip.h"
 #include "tsdf_colour.hip.h"
 #include "tsdf_extract.hip.h"
+#ifdef TSDF_EXPERIMENTS
+#include "tsdf_experiments.hip.h"
+#endif
 
 namespace {
 
@@ -54,6 +57,13 @@ int fail(int code, const char *fmt, ...)
     } while (0)
 
 constexpr int kStageSlots = 3;
+
+// The measurement build (-DTSDF_EXPERIMENTS, `make experiments`) adds the kernel variants of tsdf_experiments.hip.h.
+#ifdef TSDF_EXPERIMENTS
+constexpr bool kExperiments = true;
+#else
+constexpr bool kExperiments = false;
+#endif
 
 }  // namespace
 
@@ -374,7 +384,7 @@ constexpr int64_t kClassifyMinVoxels = 48000000;
 bool classify_one_frame(const tsdf_volume *v, int64_t launch_voxels)
 {
     if (v->variant == 7) return false;
-    return v->variant == 8 || v->variant == 12 || v->variant == 13 || launch_voxels >= kClassifyMinVoxels;
+    return v->variant == 8 || (kExperiments && v->variant >= 11 && v->variant <= 13) || launch_voxels >= kClassifyMinVoxels;
 }
 
 // Depth tile tables (summary + sparse table, tsdf_multiframe.hip.h) of n images depth[i] x mask[i] into tables[i], queued
@@ -412,34 +422,6 @@ int build_tile_tables(hipStream_t stream, const tsdf_config &c, const tsdfk::Int
     return TSDF_OK;
 }
 
-// One masked frame into one volume: tile table of depth x mask, then the class of every workgroup of the coming launch
-// (grid nbx x nby x nz; rows_per_wg as classify_workgroups takes it).  Sets p.wg_class.
-int classify_single(tsdf_volume *v, tsdfk::IntegrateParams &p, int nbx, int nby, int nz, int rows_per_wg)
-{
-    const size_t per = tile_table_elems_host(p.tiles_w, p.tiles_h);
-    if (!v->d_tiles) HIP_TRY(hipMalloc((void **)&v->d_tiles, tsdfk::kMaxFramesPerLaunch * per * sizeof(float2)));
-    const size_t n_wg = (size_t)nbx * nby * nz;
-    if (v->wg_class_bytes < n_wg) {
-        if (v->d_wg_class) HIP_TRY(hipFree(v->d_wg_class));
-        v->d_wg_class = nullptr;
-        v->wg_class_bytes = 0;
-        HIP_TRY(hipMalloc((void **)&v->d_wg_class, n_wg));
-        v->wg_class_bytes = n_wg;
-    }
-    const float *d = p.depth;
-    const uint8_t *m = p.mask;
-    int rc = build_tile_tables(v->stream, v->cfg, p, &d, &m, 1, v->d_tiles);
-    if (rc) return rc;
-    tsdfk::FramePose pose;
-    pose_from_params(pose, p);
-    pose.tiles = v->d_tiles;
-    hipLaunchKernelGGL(tsdfk::classify_workgroups, dim3((unsigned)((n_wg + 255) / 256)), dim3(256), 0, v->stream, p, pose,
-                       v->d_wg_class, nbx, nby, nz, rows_per_wg);
-    HIP_TRY(hipGetLastError());
-    p.wg_class = v->d_wg_class;
-    return TSDF_OK;
-}
-
 // The same with wavefront bricks (rows that divide into them): class per brick, then the brick kernel.  Queues the launch.
 int launch_masked_bricks(tsdf_volume *v, tsdfk::IntegrateParams &p)
 {
@@ -469,39 +451,18 @@ int launch_masked_bricks(tsdf_volume *v, tsdfk::IntegrateParams &p)
     return TSDF_OK;
 }
 
-// Kernel variants (tsdf_set_kernel_variant):
-//   0        default: integrate_tile<2, elide, nt, summary, fast> when dim_x % 4 == 0, else the scalar
-//            kernel; frame sequences (tsdf_integrate_frames_device, ..._sequence_timed) go through
-//            integrate_multi_inline, up to kMaxFramesPerLaunch (32) frames per pass over the volume
-//   3        as 0 but one launch per frame even for sequences
-//   4        as 0 with integrate_multi<R=2> (experiment; the default fuses with R=1)
-//   5        as 0 with an XCD-aware workgroup order (experiment)
-//   6        as 0 with the frame blocks staged in device memory instead of the kernarg (A/B)
-//   7        as 0 but never with the per-workgroup patch classification (the per-voxel kernel alone)
-//   8        as 0 but always with it (0 decides per launch from the previous launch's claims)
-//   9        as 0 with the workgroups of a fused launch dispatched in memory order instead of slices-fastest (A/B)
-//   10       as 0 with slices fastest but without the rotation that spreads a slice group over the XCDs (A/B)
-//   11       as 8 (always classified) with round 1's shape: 256 x 1 rows per wavefront, classified per workgroup (A/B
-//            of the brick mapping: q x r x s voxels per wavefront, classified per wavefront, the default when classifying)
-//   12       as 8 without the super-brick pre-pass (A/B)
-//   1        scalar kernel integrate_rows<1> (any dim_x)
-//   2        first version integrate_rows<4> (one row per wavefront, no elision)
-//   16 + c   experiments: c = (rsel << 2) | (elide << 1) | nt, R = 1, 2, 4 for rsel = 0, 1, 2
-//   32 + c   the same with the free-space summary (needs elide = 1)
-//   48 + c   summary + early (speculative, frustum-gated) volume loads
-//   64 + c   early loads without the summary
-//   80 + c   summary + exact shared-reciprocal projection (fast_div2)
-//   96 + c   shared-reciprocal projection without the summary
-//   112 + c  as 80 + c with the depth pixels of each workgroup's patch staged in LDS (c = 3, 7: R = 1, 2)
-constexpr int kDefaultTile = 80 + ((1 << 2) | (1 << 1) | 1);  // R = 2, elide, nt, summary, fast projection
-
-template <int R, bool ELIDE, bool NT, bool MASKED, bool SUM, bool EARLY = false, bool FAST = false>
-void launch_tile(const tsdf_volume *v, const tsdfk::IntegrateParams &p)
-{
-    dim3 block(64, 4, 1);
-    dim3 grid((p.xgroups + 63) / 64, (p.dim_y + 4 * R - 1) / (4 * R), p.nz);
-    hipLaunchKernelGGL((tsdfk::integrate_tile<R, ELIDE, NT, MASKED, SUM, EARLY, FAST>), grid, block, 0, v->stream, p);
-}
+// Kernel variants (tsdf_set_kernel_variant) of the library as shipped:
+//   0   default: one call = one launch of integrate_tile<2> (rows of a multiple of 256 voxels), of the flat kernel (other
+//       rows of a multiple of 4 voxels) or of the scalar kernel (any other row); collected frames and frame sequences
+//       (tsdf_integrate_frames_device, ..._sequence_timed) are applied up to kMaxFramesPerLaunch (32) per pass over the
+//       volume -- over the brick work list when the depth tile tables earn their keep (decided per launch from the previous
+//       launch's claims), else by the per-voxel fused kernel
+//   3   as 0 but one launch per frame even for sequences
+//   7   as 0 but never classified (the per-voxel fused kernel alone)
+//   8   as 0 but always classified
+//   1   the scalar kernel (any dim_x)
+// Every other number belongs to the measurement build (-DTSDF_EXPERIMENTS: tsdf_experiments.hip.h, `make experiments`).
+bool shipped_variant(int variant) { return variant == 0 || variant == 1 || variant == 3 || variant == 7 || variant == 8; }
 
 // Kernels that do not maintain the free-space summary must not leave stale "all ones" flags behind.
 int drop_summary(tsdf_volume *v)
@@ -539,6 +500,16 @@ double claims_read_back(const tsdf_volume *v)
     return v->claims_total > 0 ? claimed / v->claims_total : 0.0;
 }
 
+#ifdef TSDF_EXPERIMENTS
+bool experiment_variant(int variant);
+void experiment_adjust(const tsdf_volume *v, bool labels, bool *classify, int *z_fastest);
+int launch_integrate_experiment(tsdf_volume *v, const float *depth_dev, const uint8_t *mask_dev, const float *c2b);
+int launch_multi_experiment(tsdf_volume *v, tsdfk::MultiParamsInline &mi, const float *const *depth_dev, const uint8_t *const *masks_dev,
+                            const float *c2b, int n, bool labels, bool any_mask, bool classify, bool *handled, double *claims_total);
+int launch_single_experiment(tsdf_volume *v, tsdfk::IntegrateParams &common, tsdfk::FramePose &pose, const float *depth_dev,
+                             const float *c2b, bool *handled);
+#endif
+
 // Queue one Integrate launch.  Shapes are validated at tsdf_create, so the grid covers exactly
 // the slab and every access stays inside the two allocations.
 int launch_integrate(tsdf_volume *v, const float *depth_dev, const uint8_t *mask_dev,
@@ -548,90 +519,41 @@ int launch_integrate(tsdf_volume *v, const float *depth_dev, const uint8_t *mask
     const int nz = c.z_end - c.z_begin;
     if (nz == 0) return TSDF_OK;  // empty slab: nothing to do
     std::memcpy(v->last_cam2base, c2b, sizeof v->last_cam2base);
-    int variant = v->variant;
-    if (variant == 0 || (variant >= 3 && variant <= 13)) variant = kDefaultTile;
-    if (c.dim_x % 4 != 0) variant = 1;  // rows are not 16-byte aligned: scalar kernel
-    if (v->flat && variant != 1 && variant != 2) {
+#ifdef TSDF_EXPERIMENTS
+    if (c.dim_x % 4 == 0 && (v->variant == 2 || (v->variant >= 16 && !mask_dev))) return launch_integrate_experiment(v, depth_dev, mask_dev, c2b);
+#endif
+    if (c.dim_x % 4 != 0 || v->variant == 1) {
+        // rows that are not 16-byte aligned (or the scalar kernel asked for): one voxel per lane; it does not keep the summary
+        int rc = drop_summary(v);
+        if (rc) return rc;
+        const tsdfk::IntegrateParams p = make_params(v, depth_dev, mask_dev, c2b, 1);
+        dim3 block(64, 4, 1), grid((c.dim_x + 63) / 64, (c.dim_y + 3) / 4, nz);
+        if (mask_dev) hipLaunchKernelGGL((tsdfk::integrate_scalar<true>), grid, block, 0, v->stream, p);
+        else hipLaunchKernelGGL((tsdfk::integrate_scalar<false>), grid, block, 0, v->stream, p);
+        HIP_TRY(hipGetLastError());
+        return TSDF_OK;
+    }
+    if (v->flat) {
         // rows that are not a multiple of 256 voxels: the flat mapping (every lane busy, summary kept)
         return launch_multi(v, &depth_dev, mask_dev ? &mask_dev : nullptr, c2b, 1);
     }
-    const int vx = variant == 1 ? 1 : 4;
-    tsdfk::IntegrateParams p = make_params(v, depth_dev, mask_dev, c2b, vx);
-    // which launches keep the free-space summary up to date: the SUM kernels (variants >= 32 and the
-    // masked form of the tile kernel); the rows kernels and the plain tile variants do not
-    const bool summary = variant != 1 && variant != 2 &&
-                         (mask_dev != nullptr || (variant >= 32 && variant < 64) || (variant >= 80 && variant < 96) ||
-                          variant >= 112);
-    if (!summary) {
-        int rc = drop_summary(v);
-        if (rc) return rc;
-    } else {
-        v->flags_known_zero = false;
-    }
-    if (variant == 1 || variant == 2) {
-        dim3 block(64, 4, 1);
-        dim3 grid((p.xgroups + 63) / 64, (c.dim_y + 3) / 4, nz);
-        if (variant == 2) {
-            if (mask_dev) hipLaunchKernelGGL((tsdfk::integrate_rows<4, true>), grid, block, 0, v->stream, p);
-            else hipLaunchKernelGGL((tsdfk::integrate_rows<4, false>), grid, block, 0, v->stream, p);
-        } else {
-            if (mask_dev) hipLaunchKernelGGL((tsdfk::integrate_rows<1, true>), grid, block, 0, v->stream, p);
-            else hipLaunchKernelGGL((tsdfk::integrate_rows<1, false>), grid, block, 0, v->stream, p);
-        }
-    } else if (mask_dev) {
-        // masked fusion uses the default configuration; per-object volumes see their instance only, so the workgroups
-        // the tile table of depth x mask proves untouched are told to leave (variant 7: never)
-        const dim3 grid((p.xgroups + 63) / 64, (p.dim_y + 7) / 8, p.nz);
-        if (classify_one_frame(v, v->n_vox) && tiles_fit(p) && p.brick_q > 0 && v->variant != 11) {
+    tsdfk::IntegrateParams p = make_params(v, depth_dev, mask_dev, c2b, 4);
+    v->flags_known_zero = false;   // integrate_tile keeps the free-space summary up to date
+    const dim3 block(64, 4, 1), grid((p.xgroups + 63) / 64, (p.dim_y + 7) / 8, p.nz);
+    if (mask_dev) {
+        // per-object volumes see their instance only, so the bricks the tile table of depth x mask proves untouched are
+        // told to leave (variant 7: never; small launches: not worth the three small dispatches ahead of it)
+        if (classify_one_frame(v, v->n_vox) && tiles_fit(p) && p.brick_q > 0 && (!kExperiments || v->variant != 11)) {
             int rc = launch_masked_bricks(v, p);    // per wavefront brick: skipped by rows, slices and columns
             if (rc) return rc;
-        } else if (classify_one_frame(v, v->n_vox) && tiles_fit(p)) {
-            int rc = classify_single(v, p, (int)grid.x, (int)grid.y, (int)grid.z, 8);
-            if (rc) return rc;
-            hipLaunchKernelGGL((tsdfk::integrate_tile<2, true, true, true, true, false, true, false, true>), grid, dim3(64, 4, 1), 0,
-                               v->stream, p);
         } else {
-            launch_tile<2, true, true, true, true, false, true>(v, p);
-        }
-    } else if (variant >= 32) {
-        switch (variant - 32) {
-#define SUM_CASE(code, R, N, S, E) case code: launch_tile<R, true, N, false, S, E>(v, p); break;
-#define FAST_CASE(code, R, N, S) case code: launch_tile<R, true, N, false, S, false, true>(v, p); break;
-            FAST_CASE(48 + 2, 1, false, true) FAST_CASE(48 + 3, 1, true, true)
-            FAST_CASE(48 + 6, 2, false, true) FAST_CASE(48 + 7, 2, true, true)
-            FAST_CASE(48 + 10, 4, false, true) FAST_CASE(48 + 11, 4, true, true)
-            FAST_CASE(64 + 2, 1, false, false) FAST_CASE(64 + 3, 1, true, false)
-            FAST_CASE(64 + 6, 2, false, false) FAST_CASE(64 + 7, 2, true, false)
-            FAST_CASE(64 + 10, 4, false, false) FAST_CASE(64 + 11, 4, true, false)
-#undef FAST_CASE
-            case 80 + 3: hipLaunchKernelGGL((tsdfk::integrate_tile<1, true, true, false, true, false, true, true>),
-                                            dim3((p.xgroups + 63) / 64, (p.dim_y + 3) / 4, p.nz), dim3(64, 4, 1), 0, v->stream, p); break;
-            case 80 + 7: hipLaunchKernelGGL((tsdfk::integrate_tile<2, true, true, false, true, false, true, true>),
-                                            dim3((p.xgroups + 63) / 64, (p.dim_y + 7) / 8, p.nz), dim3(64, 4, 1), 0, v->stream, p); break;
-            SUM_CASE(2, 1, false, true, false) SUM_CASE(3, 1, true, true, false)
-            SUM_CASE(6, 2, false, true, false) SUM_CASE(7, 2, true, true, false)
-            SUM_CASE(10, 4, false, true, false) SUM_CASE(11, 4, true, true, false)
-            SUM_CASE(16 + 2, 1, false, true, true) SUM_CASE(16 + 3, 1, true, true, true)
-            SUM_CASE(16 + 6, 2, false, true, true) SUM_CASE(16 + 7, 2, true, true, true)
-            SUM_CASE(16 + 10, 4, false, true, true) SUM_CASE(16 + 11, 4, true, true, true)
-            SUM_CASE(32 + 2, 1, false, false, true) SUM_CASE(32 + 3, 1, true, false, true)
-            SUM_CASE(32 + 6, 2, false, false, true) SUM_CASE(32 + 7, 2, true, false, true)
-            SUM_CASE(32 + 10, 4, false, false, true) SUM_CASE(32 + 11, 4, true, false, true)
-#undef SUM_CASE
-            default: return fail(TSDF_ERR_INVALID, "unknown kernel variant %d", variant);
+#ifdef TSDF_EXPERIMENTS
+            if (v->variant == 11 && classify_one_frame(v, v->n_vox) && tiles_fit(p)) return launch_integrate_experiment(v, depth_dev, mask_dev, c2b);
+#endif
+            hipLaunchKernelGGL((tsdfk::integrate_tile<2, true>), grid, block, 0, v->stream, p);
         }
     } else {
-        switch (variant - 16) {
-#define TILE_CASE(code, R, E, N) case code: launch_tile<R, E, N, false, false>(v, p); break;
-            TILE_CASE(0, 1, false, false) TILE_CASE(1, 1, false, true)
-            TILE_CASE(2, 1, true, false)  TILE_CASE(3, 1, true, true)
-            TILE_CASE(4, 2, false, false) TILE_CASE(5, 2, false, true)
-            TILE_CASE(6, 2, true, false)  TILE_CASE(7, 2, true, true)
-            TILE_CASE(8, 4, false, false) TILE_CASE(9, 4, false, true)
-            TILE_CASE(10, 4, true, false) TILE_CASE(11, 4, true, true)
-#undef TILE_CASE
-            default: return fail(TSDF_ERR_INVALID, "unknown kernel variant %d", variant);
-        }
+        hipLaunchKernelGGL((tsdfk::integrate_tile<2, false>), grid, block, 0, v->stream, p);
     }
     HIP_TRY(hipGetLastError());
     return TSDF_OK;
@@ -655,26 +577,26 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
         fp.label_im = label_ims ? label_ims[f] : nullptr;
         fp.score_im = label_ims ? score_ims[f] : nullptr;
     };
+    const dim3 block(64, 4, 1);
     if (n == 1 && !label_ims) {   // pose by value: nothing to stage
         tsdfk::IntegrateParams common = make_params(v, depth_dev[0], nullptr, c2b, 4);
         tsdfk::FramePose pose;
         fill_pose(pose, 0);
         std::memcpy(v->last_cam2base, c2b, sizeof v->last_cam2base);
         v->flags_known_zero = false;
-        dim3 block(64, 4, 1);
-        if (v->flat && pose.mask != nullptr && classify_one_frame(v, v->n_vox) && tiles_fit(common) && common.brick_q > 0 &&
-            v->variant != 11) {
+#ifdef TSDF_EXPERIMENTS
+        {
+            bool handled = false;
+            int rc = launch_single_experiment(v, common, pose, depth_dev[0], c2b, &handled);
+            if (rc || handled) return rc;
+        }
+#endif
+        if (v->flat && pose.mask != nullptr && classify_one_frame(v, v->n_vox) && tiles_fit(common) && common.brick_q > 0) {
+            // one masked frame into a flat-mapped volume (the reference's 200^3 object grids), large enough to repay a class table
             tsdfk::IntegrateParams cp = make_params(v, depth_dev[0], pose.mask, c2b, 4);
             return launch_masked_bricks(v, cp);
-        } else if (v->flat && pose.mask != nullptr && classify_one_frame(v, v->n_vox) && tiles_fit(common)) {
-            // one masked frame into a flat-mapped volume (the reference's 200^3 object grids): classified per workgroup
-            dim3 grid((v->chunks_per_slice + 3) / 4, 1, nz);
-            tsdfk::IntegrateParams cp = make_params(v, depth_dev[0], pose.mask, c2b, 4);
-            int rc = classify_single(v, cp, (int)grid.x, 1, nz, 0);
-            if (rc) return rc;
-            common.wg_class = cp.wg_class;
-            hipLaunchKernelGGL((tsdfk::integrate_multi_single<true, true, true>), grid, block, 0, v->stream, common, pose);
-        } else if (v->flat) {
+        }
+        if (v->flat) {
             dim3 grid((v->chunks_per_slice + 3) / 4, 1, nz);
             hipLaunchKernelGGL((tsdfk::integrate_multi_single<true, true>), grid, block, 0, v->stream, common, pose);
         } else {
@@ -685,217 +607,149 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
         return TSDF_OK;
     }
     std::memcpy(v->last_cam2base, c2b + 16 * (n - 1), sizeof v->last_cam2base);
-    v->flags_known_zero = false;   // integrate_multi maintains the summary
-    dim3 block(64, 4, 1);
-    if (label_ims || (v->variant != 4 && v->variant != 5 && v->variant != 6)) {   // frame blocks in the kernarg: nothing staged
-        tsdfk::MultiParamsInline mi;
-        mi.common = make_params(v, depth_dev[0], nullptr, c2b, 4);
-        mi.n_frames = n;
-        for (int f = 0; f < n; ++f) fill_pose(mi.frames[f], f);
-        for (int f = n; f < tsdfk::kMaxFramesPerLaunch; ++f) mi.frames[f] = mi.frames[0];
-        mi.labels.label = v->d_label; mi.labels.fp = v->d_fp; mi.labels.bp = v->d_bp; mi.labels.prob_thd = v->prob_thd;
-        // Workgroup order of a fused launch: slices fastest (variant 9: memory order, the A/B).  Consecutively dispatched
-        // workgroups then share their (x, y) footprint, i.e. the windows of the launch's up to 32 depth frames (39 MB,
-        // more than the L2s hold) they gather from.  Measured at 512^3 S-surf with a depth frame per pose: 0.1325 ->
-        // 0.1148 ms per frame; 1024^3 on the fr3 trajectory 0.529 -> 0.376; no change with one resident frame.
-        mi.z_fastest = v->variant == 9 ? 0 : (v->variant == 10 ? 1 : 2);   // variant 10: slices fastest, not rotated (A/B)
-        {
-            bool any_mask = false;
-            for (int f = 0; f < n && masks_dev; ++f) any_mask = any_mask || masks_dev[f] != nullptr;
-            dim3 grid_flat((v->chunks_per_slice + 3) / 4, 1, nz), grid_rows((mi.common.xgroups + 63) / 64, (c.dim_y + 3) / 4, nz);
-            if (mi.z_fastest) {
-                std::swap(grid_flat.x, grid_flat.z);
-                std::swap(grid_rows.x, grid_rows.z);
-            }
-            // patch classification: frames without masks, tables of at most 4 MiB per frame
-            // Variant 8: always; variant 7: never; default: while it pays -- the first launch classifies, every
-            // classifying launch counts its claims, and a launch whose predecessor claimed less than a tenth of its
-            // workgroup-frames goes without (the tables and the prologue cost more than that saves), with a new probe
-            // every eighth launch.  The count is read back asynchronously: a decision never waits for the GPU.
-            if (v->claims_pending) {
-                const hipError_t qe = hipEventQuery(v->claims_done);
-                if (qe == hipSuccess) {
-                    v->claim_fraction = claims_read_back(v);
-                    v->claims_pending = false;
-                    v->claims_known = true;
-                } else if (qe == hipErrorNotReady) {
-                    (void)hipGetLastError();   // "not ready" is an answer, not an error to be found by a later check
-                } else {
-                    // a real failure: forget the stale count (the next launch classifies and counts afresh) and report it
-                    v->claims_pending = false;
-                    v->claims_known = false;
-                    (void)hipGetLastError();
-                    return fail(TSDF_ERR_HIP, "claims read-back: hipEventQuery failed: %s", hipGetErrorString(qe));
-                }
-            }
-            bool classify = tiles_fit(mi.common) && v->variant != 7;
-            // label launches classify only through bricks (a claimed wavefront-frame carries no label evidence either:
-            // skipped = not observed, free space = outside the truncation band)
-            if (label_ims && (mi.common.brick_q == 0 || v->variant == 11)) classify = false;
-            if (classify && v->variant != 8 && v->variant != 11 && v->variant != 12 && v->variant != 13)
-                classify = !v->claims_known || v->claim_fraction >= 0.10 || v->launches_unclassified >= 7;
-            v->launches_unclassified = classify ? 0 : v->launches_unclassified + 1;
-            const bool count_claims = classify && !v->claims_pending;
-            if (classify && !v->d_claims) {
-                // the launch's counter block (tsdf_multiframe.hip.h, kListBuckets): per bucket the length of its brick sub-list and
-                // its share of the claims; cleared by the table kernel below.  Kernels with one claim counter use bucket 0's.
-                HIP_TRY(hipMalloc((void **)&v->d_claims, tsdfk::kCounterBytes + sizeof(tsdfk::ClassPoseTable)));   // + the frames' table
-                HIP_TRY(hipHostMalloc((void **)&v->h_claims, tsdfk::kCounterBytes, hipHostMallocDefault));
-                HIP_TRY(hipEventCreateWithFlags(&v->claims_done, hipEventDisableTiming));
-            }
-            if (count_claims) mi.common.claim_counter = v->d_claims + 1;   // bucket 0's claims word
-            if (classify) {
-                // depth tile tables of the n frames (two small launches), then the kernel that consults them
-                const size_t per_frame = tile_table_elems_host(mi.common.tiles_w, mi.common.tiles_h);
-                if (!v->d_tiles) HIP_TRY(hipMalloc((void **)&v->d_tiles, tsdfk::kMaxFramesPerLaunch * per_frame * sizeof(float2)));
-                int rc = build_tile_tables(v->stream, c, mi.common, depth_dev, masks_dev, n, v->d_tiles, v->d_claims);
-                if (rc) return rc;
-                for (int f = 0; f < n; ++f) mi.frames[f].tiles = v->d_tiles + (size_t)f * per_frame;
-                for (int f = n; f < tsdfk::kMaxFramesPerLaunch; ++f) mi.frames[f] = mi.frames[0];
-            }
-            // classified launches use the brick view wherever a row divides into bricks (variant 11: round 1's shapes --
-            // rows / 1024 consecutive voxels, classified per workgroup -- for A/B and tests)
-            const bool bricks = classify && v->variant != 11 && mi.common.brick_q > 0;
-            dim3 grid_bricks(1, 1, 1);
-            const int nz_groups = (nz + mi.common.brick_s - 1) / mi.common.brick_s;   // a brick spans brick_s slices
-            if (bricks) {
-                const unsigned wgs = (unsigned)(((int64_t)mi.common.brick_groups * mi.common.bricks_per_group + 3) / 4);
-                if (wgs > 65535u) mi.z_fastest = 0;   // the slow grid dimensions hold 65535 at most
-                grid_bricks = mi.z_fastest ? dim3((unsigned)nz_groups, 1, wgs) : dim3(wgs, 1, (unsigned)nz_groups);
-            }
-            mi.super_mask = nullptr;
-            mi.nz_super = 1;
-            // the default: a pre-pass compacts the live bricks into a work list and the launch runs one wavefront per entry
-            // (variants 12 / 13: the first version for A/B -- a workgroup per four bricks of the whole slab, classified in its
-            // prologue, without / with the super-brick table)
-            const bool brick_list = bricks && v->variant != 12 && v->variant != 13;
-            if (brick_list) {
-                const int64_t per_group = (int64_t)mi.common.brick_groups * mi.common.bricks_per_group;
-                tsdfk::BrickListParams bl;
-                bl.nsx = (mi.common.bricks_per_group + tsdfk::kSuperBX - 1) / tsdfk::kSuperBX;
-                bl.nsy = (mi.common.brick_groups + tsdfk::kSuperBY - 1) / tsdfk::kSuperBY;
-                bl.nsz = (nz_groups + tsdfk::kSuperBZ - 1) / tsdfk::kSuperBZ;
-                const int64_t n_super = (int64_t)bl.nsx * bl.nsy * bl.nsz;
-                // a sub-list must hold every brick of every super-brick its hash deals to it: counted exactly, once per grid shape
-                if (v->work_nsuper != n_super) {
-                    std::vector<int64_t> per((size_t)tsdfk::kListBuckets, 0);
-                    for (int64_t id = 0; id < n_super; ++id) ++per[(size_t)(((uint32_t)id * 2654435761u) >> 26)];   // as classify_brick_list
-                    v->work_bucket_supers = *std::max_element(per.begin(), per.end());
-                    v->work_nsuper = n_super;
-                }
-                const int64_t cap = v->work_bucket_supers * tsdfk::kSuperBricks;
-                const int64_t total = cap * tsdfk::kListBuckets;
-                if (total > 0x7fffffffll - 4) return fail(TSDF_ERR_INVALID, "fused launch: %lld bricks exceed the work list's 32-bit index", (long long)total);
-                if (v->work_entries < (size_t)total) {
-                    if (v->d_work) HIP_TRY(hipFree(v->d_work));
-                    v->d_work = nullptr;
-                    v->work_entries = 0;
-                    HIP_TRY(hipMalloc((void **)&v->d_work, ((size_t)total + 4) * sizeof(uint4)));   // + the last, partial workgroup's reads
-                    v->work_entries = (size_t)total;
-                }
-                bl.list = v->d_work;
-                bl.counters = reinterpret_cast<unsigned char *>(v->d_claims);
-                bl.bucket_cap = (unsigned int)cap;
-                bl.poses = reinterpret_cast<tsdfk::ClassPoseTable *>(bl.counters + tsdfk::kCounterBytes);
-                hipLaunchKernelGGL(tsdfk::classify_brick_list, dim3((unsigned)((n_super + 3) / 4)), block, 0, v->stream, mi, bl);
-                const dim3 grid_list((unsigned)(((cap + 3) / 4 + 1) * tsdfk::kListBuckets));   // front groups + back groups of every sub-list
-                const uint4 *wl = v->d_work;
-                const unsigned char *wc = bl.counters;
-                if (label_ims)
-                    hipLaunchKernelGGL((tsdfk::integrate_brick_list<true, true, false>), grid_list, block, 0, v->stream, mi, wl, wc, bl.bucket_cap, (const tsdfk::ClassPoseTable *)bl.poses);
-                else if (any_mask)
-                    hipLaunchKernelGGL((tsdfk::integrate_brick_list<true, false, true>), grid_list, block, 0, v->stream, mi, wl, wc, bl.bucket_cap, (const tsdfk::ClassPoseTable *)bl.poses);
-                else
-                    hipLaunchKernelGGL((tsdfk::integrate_brick_list<true, false, false>), grid_list, block, 0, v->stream, mi, wl, wc, bl.bucket_cap, (const tsdfk::ClassPoseTable *)bl.poses);
-                grid_bricks = dim3((unsigned)per_group, 1, (unsigned)nz_groups);   // for the claim statistics: wavefront-frames = bricks x frames
-            }
-            else
-            if (bricks && v->variant != 12) {   // variant 13: the first version with its super-brick table (A/B)
-                const unsigned wgs = (unsigned)(((int64_t)mi.common.brick_groups * mi.common.bricks_per_group + 3) / 4);
-                mi.nz_super = (nz_groups + tsdfk::kSuperZ - 1) / tsdfk::kSuperZ;
-                const size_t words = (size_t)wgs * mi.nz_super;
-                if (v->super_words < words) {
-                    if (v->d_super) HIP_TRY(hipFree(v->d_super));
-                    v->d_super = nullptr;
-                    v->super_words = 0;
-                    HIP_TRY(hipMalloc((void **)&v->d_super, words * sizeof(unsigned int)));
-                    v->super_words = words;
-                }
-                hipLaunchKernelGGL(tsdfk::classify_superbricks, dim3((unsigned)((words + 3) / 4)), block, 0, v->stream, mi, v->d_super, (int)wgs);
-                mi.super_mask = v->d_super;
-            }
-            if (brick_list)
-                ;   // launched above
-            else if (bricks && label_ims)
-                hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, true, false, true, true>), grid_bricks, block, 0, v->stream, mi);
-            else if (label_ims && v->flat)
-                hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, true, true, false>), grid_flat, block, 0, v->stream, mi);
-            else if (label_ims)
-                hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, true, false>), grid_rows, block, 0, v->stream, mi);
-            else if (bricks && any_mask)
-                hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, false, true, true, true>), grid_bricks, block, 0, v->stream, mi);
-            else if (bricks)
-                hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, false, false, true, true>), grid_bricks, block, 0, v->stream, mi);
-            else if (v->flat && any_mask && classify)
-                hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, true, false, true, true>), grid_flat, block, 0, v->stream, mi);
-            else if (!v->flat && any_mask && classify)
-                hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, false, true, true>), grid_rows, block, 0, v->stream, mi);
-            else if (v->flat && any_mask)
-                hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, true, false, true>), grid_flat, block, 0, v->stream, mi);
-            else if (v->flat && classify)
-                hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, true, false, false, true>), grid_flat, block, 0, v->stream, mi);
-            else if (v->flat)
-                hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, true, false, false>), grid_flat, block, 0, v->stream, mi);
-            else if (any_mask)
-                hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, false, true>), grid_rows, block, 0, v->stream, mi);
-            else if (classify)
-                hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, false, false, true>), grid_rows, block, 0, v->stream, mi);
-            else
-                hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, false, false>), grid_rows, block, 0, v->stream, mi);
-            if (count_claims) {
-                const dim3 &g = bricks ? grid_bricks : v->flat ? grid_flat : grid_rows;
-                // claims are counted per workgroup-frame, with bricks per wavefront-frame (four per workgroup)
-                v->claims_total = (double)g.x * g.y * g.z * n * ((bricks && !brick_list) ? 4.0 : 1.0);
-                HIP_TRY(hipMemcpyAsync(v->h_claims, v->d_claims, tsdfk::kCounterBytes, hipMemcpyDeviceToHost, v->stream));
-                HIP_TRY(hipEventRecord(v->claims_done, v->stream));
-                v->claims_pending = true;
-            }
+    v->flags_known_zero = false;   // the fused kernels maintain the summary
+    // the frame blocks travel in the kernarg: nothing is staged on the stream ahead of the launch
+    tsdfk::MultiParamsInline mi;
+    mi.common = make_params(v, depth_dev[0], nullptr, c2b, 4);
+    mi.n_frames = n;
+    for (int f = 0; f < n; ++f) fill_pose(mi.frames[f], f);
+    for (int f = n; f < tsdfk::kMaxFramesPerLaunch; ++f) mi.frames[f] = mi.frames[0];
+    mi.labels.label = v->d_label; mi.labels.fp = v->d_fp; mi.labels.bp = v->d_bp; mi.labels.prob_thd = v->prob_thd;
+    bool any_mask = false;
+    for (int f = 0; f < n && masks_dev; ++f) any_mask = any_mask || masks_dev[f] != nullptr;
+
+    // Patch classification: tables of at most 4 MiB per frame.  Variant 8: always; variant 7: never;
+    // default: while it pays -- the first launch classifies, every classifying launch counts its claims, and a launch whose
+    // predecessor claimed less than a tenth of its wavefront-frames goes without (the tables and the pre-pass cost more than
+    // that saves), with a new probe every eighth launch.  The count is read back asynchronously: a decision never waits
+    // for the GPU.
+    if (v->claims_pending) {
+        const hipError_t qe = hipEventQuery(v->claims_done);
+        if (qe == hipSuccess) {
+            v->claim_fraction = claims_read_back(v);
+            v->claims_pending = false;
+            v->claims_known = true;
+        } else if (qe == hipErrorNotReady) {
+            (void)hipGetLastError();   // "not ready" is an answer, not an error to be found by a later check
+        } else {
+            // a real failure: forget the stale count (the next launch classifies and counts afresh) and report it
+            v->claims_pending = false;
+            v->claims_known = false;
+            (void)hipGetLastError();
+            return fail(TSDF_ERR_HIP, "claims read-back: hipEventQuery failed: %s", hipGetErrorString(qe));
         }
-        HIP_TRY(hipGetLastError());
-        return TSDF_OK;
     }
-    // experiments (variants 4, 5, 6): frame blocks staged in device memory
-    const int s = v->frames_next;
-    v->frames_next = (s + 1) % kStageSlots;
-    const size_t bytes = tsdfk::kMaxFramesPerLaunch * sizeof(tsdfk::FramePose);
-    if (!v->h_frames[s]) {
-        HIP_TRY(hipHostMalloc((void **)&v->h_frames[s], bytes, hipHostMallocDefault));
-        HIP_TRY(hipMalloc((void **)&v->d_frames[s], bytes));
-        HIP_TRY(hipEventCreateWithFlags(&v->frames_done[s], hipEventDisableTiming));
+    // classified launches run over wavefront bricks (every grid whose rows are a multiple of 4 voxels has a brick view)
+    bool classify = tiles_fit(mi.common) && v->variant != 7 && mi.common.brick_q > 0;
+    mi.z_fastest = 2;
+#ifdef TSDF_EXPERIMENTS
+    experiment_adjust(v, label_ims != nullptr, &classify, &mi.z_fastest);
+#endif
+    const bool forced = v->variant == 8 || (kExperiments && v->variant >= 11 && v->variant <= 13);
+    if (classify && !forced) classify = !v->claims_known || v->claim_fraction >= 0.10 || v->launches_unclassified >= 7;
+    v->launches_unclassified = classify ? 0 : v->launches_unclassified + 1;
+    const bool count_claims = classify && !v->claims_pending;
+    if (classify && !v->d_claims) {
+        // the launch's counter block (tsdf_multiframe.hip.h, kListBuckets): per bucket the lengths of its brick sub-list and
+        // its share of the claims, cleared by the table kernel below; behind it the frames' table for classify_patch
+        HIP_TRY(hipMalloc((void **)&v->d_claims, tsdfk::kCounterBytes + sizeof(tsdfk::ClassPoseTable)));
+        HIP_TRY(hipHostMalloc((void **)&v->h_claims, tsdfk::kCounterBytes, hipHostMallocDefault));
+        HIP_TRY(hipEventCreateWithFlags(&v->claims_done, hipEventDisableTiming));
     }
-    if (v->frames_used[s]) HIP_TRY(hipEventSynchronize(v->frames_done[s]));
-    tsdfk::MultiParams mp;
-    mp.common = make_params(v, depth_dev[0], nullptr, c2b, 4);
-    mp.frames = v->d_frames[s];
-    mp.n_frames = n;
-    for (int f = 0; f < n; ++f) fill_pose(v->h_frames[s][f], f);
-    HIP_TRY(hipMemcpyAsync(v->d_frames[s], v->h_frames[s], n * sizeof(tsdfk::FramePose), hipMemcpyHostToDevice, v->stream));
-    if (v->flat) {
-        dim3 grid((v->chunks_per_slice + 3) / 4, 1, nz);
-        hipLaunchKernelGGL((tsdfk::integrate_multi<1, true, true>), grid, block, 0, v->stream, mp);
-    } else if (v->variant == 5) {   // experiment: XCD-aware block order
-        dim3 grid((mp.common.xgroups + 63) / 64, (c.dim_y + 3) / 4, nz);
-        hipLaunchKernelGGL((tsdfk::integrate_multi_xcd<true>), grid, block, 0, v->stream, mp);
-    } else if (v->variant == 4) {   // experiment: two rows per lane
-        dim3 grid((mp.common.xgroups + 63) / 64, (c.dim_y + 7) / 8, nz);
-        hipLaunchKernelGGL((tsdfk::integrate_multi<2, true, false>), grid, block, 0, v->stream, mp);
-    } else {                        // variant 6: the default kernel with staged frame blocks (A/B of the kernarg path)
-        dim3 grid((mp.common.xgroups + 63) / 64, (c.dim_y + 3) / 4, nz);
-        hipLaunchKernelGGL((tsdfk::integrate_multi<1, true, false>), grid, block, 0, v->stream, mp);
+    if (count_claims) mi.common.claim_counter = v->d_claims + 1;   // bucket 0's claims word (the pre-pass adds the bucket's offset)
+    if (classify) {
+        // depth tile tables of the n frames (two small launches), then the kernels that consult them
+        const size_t per_frame = tile_table_elems_host(mi.common.tiles_w, mi.common.tiles_h);
+        if (!v->d_tiles) HIP_TRY(hipMalloc((void **)&v->d_tiles, tsdfk::kMaxFramesPerLaunch * per_frame * sizeof(float2)));
+        int rc = build_tile_tables(v->stream, c, mi.common, depth_dev, masks_dev, n, v->d_tiles, v->d_claims);
+        if (rc) return rc;
+        for (int f = 0; f < n; ++f) mi.frames[f].tiles = v->d_tiles + (size_t)f * per_frame;
+        for (int f = n; f < tsdfk::kMaxFramesPerLaunch; ++f) mi.frames[f] = mi.frames[0];
+    }
+    const int nz_groups = (nz + mi.common.brick_s - 1) / mi.common.brick_s;   // a brick spans brick_s slices
+    double claims_total = 0.0;
+    bool launched = false;
+#ifdef TSDF_EXPERIMENTS
+    {
+        int rc = launch_multi_experiment(v, mi, depth_dev, masks_dev, c2b, n, label_ims != nullptr, any_mask, classify, &launched, &claims_total);
+        if (rc) return rc;
+    }
+#endif
+    if (!launched && classify) {
+        // A pre-pass compacts the bricks some frame may touch into a work list and the launch runs one wavefront per entry.
+        const int64_t per_group = (int64_t)mi.common.brick_groups * mi.common.bricks_per_group;
+        tsdfk::BrickListParams bl;
+        bl.nsx = (mi.common.bricks_per_group + tsdfk::kSuperBX - 1) / tsdfk::kSuperBX;
+        bl.nsy = (mi.common.brick_groups + tsdfk::kSuperBY - 1) / tsdfk::kSuperBY;
+        bl.nsz = (nz_groups + tsdfk::kSuperBZ - 1) / tsdfk::kSuperBZ;
+        const int64_t n_super = (int64_t)bl.nsx * bl.nsy * bl.nsz;
+        // a sub-list must hold every brick of every super-brick its hash deals to it: counted exactly, once per grid shape
+        if (v->work_nsuper != n_super) {
+            std::vector<int64_t> per((size_t)tsdfk::kListBuckets, 0);
+            for (int64_t id = 0; id < n_super; ++id) ++per[(size_t)(((uint32_t)id * 2654435761u) >> 26)];   // as classify_brick_list
+            v->work_bucket_supers = *std::max_element(per.begin(), per.end());
+            v->work_nsuper = n_super;
+        }
+        const int64_t cap = v->work_bucket_supers * tsdfk::kSuperBricks;
+        const int64_t total = cap * tsdfk::kListBuckets;
+        if (total > 0x7fffffffll - 1024) return fail(TSDF_ERR_INVALID, "fused launch: %lld bricks exceed the work list's 32-bit index", (long long)total);
+        if (v->work_entries < (size_t)total) {
+            if (v->d_work) HIP_TRY(hipFree(v->d_work));
+            v->d_work = nullptr;
+            v->work_entries = 0;
+            HIP_TRY(hipMalloc((void **)&v->d_work, (size_t)total * sizeof(uint4)));
+            v->work_entries = (size_t)total;
+        }
+        bl.list = v->d_work;
+        bl.counters = reinterpret_cast<unsigned char *>(v->d_claims);
+        bl.bucket_cap = (unsigned int)cap;
+        bl.poses = reinterpret_cast<tsdfk::ClassPoseTable *>(bl.counters + tsdfk::kCounterBytes);
+        hipLaunchKernelGGL(tsdfk::classify_brick_list, dim3((unsigned)((n_super + 3) / 4)), block, 0, v->stream, mi, bl);
+        const dim3 grid_list((unsigned)(((cap + 3) / 4 + 1) * tsdfk::kListBuckets));   // front groups + back groups of every sub-list
+        const uint4 *wl = v->d_work;
+        const unsigned char *wc = bl.counters;
+        const tsdfk::ClassPoseTable *wp = bl.poses;
+        if (label_ims)
+            hipLaunchKernelGGL((tsdfk::integrate_brick_list<true, true, false>), grid_list, block, 0, v->stream, mi, wl, wc, bl.bucket_cap, wp);
+        else if (any_mask)
+            hipLaunchKernelGGL((tsdfk::integrate_brick_list<true, false, true>), grid_list, block, 0, v->stream, mi, wl, wc, bl.bucket_cap, wp);
+        else
+            hipLaunchKernelGGL((tsdfk::integrate_brick_list<true, false, false>), grid_list, block, 0, v->stream, mi, wl, wc, bl.bucket_cap, wp);
+        claims_total = (double)per_group * nz_groups * n;   // wavefront-frames = bricks x frames
+        launched = true;
+    }
+    if (!launched) {
+        // The per-voxel fused kernel.  Workgroup order: slices fastest -- consecutively dispatched workgroups share their
+        // (x, y) footprint, i.e. the windows of the launch's up to 32 depth frames (39 MB, more than the L2s hold) they gather
+        // from (512^3 S-surf with a depth frame per pose: 0.1325 -> 0.1148 ms per frame; 1024^3 fr3 trajectory 0.529 ->
+        // 0.376) -- and rotated, (z + x + y) mod n, so that a slice group's workgroups are spread over all eight XCDs.
+        dim3 grid_flat((v->chunks_per_slice + 3) / 4, 1, nz), grid_rows((mi.common.xgroups + 63) / 64, (c.dim_y + 3) / 4, nz);
+        const dim3 &g0 = v->flat ? grid_flat : grid_rows;
+        if (g0.x > 65535u) mi.z_fastest = 0;   // slices fastest puts the blocks of a slice into grid.z: 65535 at most (then: memory order)
+        if (mi.z_fastest) {
+            std::swap(grid_flat.x, grid_flat.z);
+            std::swap(grid_rows.x, grid_rows.z);
+        }
+        if (label_ims && v->flat)
+            hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, true, true, false>), grid_flat, block, 0, v->stream, mi);
+        else if (label_ims)
+            hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, true, false>), grid_rows, block, 0, v->stream, mi);
+        else if (v->flat && any_mask)
+            hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, true, false, true>), grid_flat, block, 0, v->stream, mi);
+        else if (v->flat)
+            hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, true, false, false>), grid_flat, block, 0, v->stream, mi);
+        else if (any_mask)
+            hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, false, true>), grid_rows, block, 0, v->stream, mi);
+        else
+            hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, false, false>), grid_rows, block, 0, v->stream, mi);
+    }
+    if (count_claims) {
+        v->claims_total = claims_total;
+        HIP_TRY(hipMemcpyAsync(v->h_claims, v->d_claims, tsdfk::kCounterBytes, hipMemcpyDeviceToHost, v->stream));
+        HIP_TRY(hipEventRecord(v->claims_done, v->stream));
+        v->claims_pending = true;
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(v->frames_done[s], v->stream));
-    v->frames_used[s] = true;
     return TSDF_OK;
 }
 
@@ -909,7 +763,8 @@ int frames_per_launch(const tsdf_volume *)
 
 bool can_fuse(const tsdf_volume *v)
 {
-    return (v->variant == 0 || (v->variant >= 4 && v->variant <= 13)) && v->cfg.dim_x % 4 == 0;
+    // (the measurement build's variants 4 .. 13 are flavours of the fused path)
+    return (v->variant == 0 || v->variant == 7 || v->variant == 8 || (kExperiments && v->variant >= 4 && v->variant <= 13)) && v->cfg.dim_x % 4 == 0;
 }
 
 // A sequence of frames: fused frames_per_launch() at a time when the default kernel is selected.
@@ -1118,13 +973,20 @@ int write_bin(const char *path, int dx, int dy, int dz, const float origin[3], f
     return TSDF_OK;
 }
 
+#ifdef TSDF_EXPERIMENTS
+#include "tsdf_experiments_host.hip.h"
+#endif
+
 }  // namespace
 
 extern "C" {
 
 const char *tsdf_last_error(void) { return g_last_error.c_str(); }
 
-const char *tsdf_version(void) { return "tsdf_hip 0.1 (gfx950)"; }
+const char *tsdf_version(void)
+{
+    return kExperiments ? "tsdf_hip 0.3 (gfx950) +experiments" : "tsdf_hip 0.3 (gfx950)";
+}
 
 void tsdf_multiply_matrix(const float a[16], const float b[16], float out[16])
 {
@@ -1585,8 +1447,7 @@ int tsdf_classification_info(tsdf_volume *v, double info_out[2])
 int32_t tsdf_frames_per_launch(const tsdf_volume *v)
 {
     if (!v) return 0;
-    const bool fuse = (v->variant == 0 || (v->variant >= 4 && v->variant <= 13)) && v->cfg.dim_x % 4 == 0;
-    return fuse ? frames_per_launch(v) : 1;
+    return can_fuse(v) ? frames_per_launch(v) : 1;
 }
 
 int tsdf_get_config(const tsdf_volume *v, tsdf_config *out)
@@ -1623,10 +1484,13 @@ int tsdf_get_stream(tsdf_volume *v, void **hip_stream)
 int tsdf_set_kernel_variant(tsdf_volume *v, int32_t variant)
 {
     if (!v) return fail(TSDF_ERR_INVALID, "tsdf_set_kernel_variant: NULL handle");
-    const int c = (variant - 32) & 15;
-    const bool sum_ok = (variant >= 32 && variant < 112 && c < 12 && ((c >> 1) & 1)) || variant == 115 || variant == 119;
-    if (!(variant >= 0 && variant <= 13) && !(variant >= 16 && variant < 28) && !sum_ok)
-        return fail(TSDF_ERR_INVALID, "tsdf_set_kernel_variant: unknown variant %d", variant);
+    bool ok = shipped_variant(variant);
+#ifdef TSDF_EXPERIMENTS
+    ok = ok || experiment_variant(variant);
+#endif
+    if (!ok)
+        return fail(TSDF_ERR_INVALID, "tsdf_set_kernel_variant: unknown variant %d (this build knows 0, 1, 3, 7, 8%s)", variant,
+                    kExperiments ? " and the experiments" : "; the others live in the -DTSDF_EXPERIMENTS build");
     v->variant = variant;
     return TSDF_OK;
 }
@@ -2342,14 +2206,14 @@ int tsdf_batch_integrate_device(tsdf_batch *b, const float *depth_dev, const uin
     int64_t launch_voxels = 0;
     for (tsdf_volume *v : b->vols) launch_voxels += v->n_vox;
     // ... and not for many small volumes: one tile table per object has to be built per frame (64 x 100^3: 0.231 -> 0.262 ms)
-    const bool big_enough = b->vols[0]->variant == 8 || b->vols[0]->variant == 12 || b->vols[0]->variant == 13 || launch_voxels >= (int64_t)n * 2000000;
+    const bool big_enough = b->vols[0]->variant == 8 || (kExperiments && b->vols[0]->variant >= 11 && b->vols[0]->variant <= 13) || launch_voxels >= (int64_t)n * 2000000;
     const bool classify = any_mask && same_range && big_enough && classify_one_frame(b->vols[0], launch_voxels) &&
                           tiles_fit(b->h_params[s][0]);
     if (classify) {
         const size_t per = tile_table_elems_host(b->h_params[s][0].tiles_w, b->h_params[s][0].tiles_h);
         if (!b->d_tiles) {
             HIP_TRY(hipMalloc((void **)&b->d_tiles, (size_t)n * per * sizeof(float2)));
-            HIP_TRY(hipMalloc((void **)&b->d_wg_class, (size_t)b->max_blocks * b->total_slices));
+            if (kExperiments) HIP_TRY(hipMalloc((void **)&b->d_wg_class, (size_t)b->max_blocks * b->total_slices));
             b->tiles_per_object = per;
         }
         std::vector<const float *> depths((size_t)n, depth_dev);
@@ -2360,9 +2224,9 @@ int tsdf_batch_integrate_device(tsdf_batch *b, const float *depth_dev, const uin
     HIP_TRY(hipMemcpyAsync(b->d_params[s], b->h_params[s], n * sizeof(tsdfk::IntegrateParams), hipMemcpyHostToDevice, b->stream));
     HIP_TRY(hipMemcpyAsync(b->d_poses[s], b->h_poses[s], n * sizeof(tsdfk::FramePose), hipMemcpyHostToDevice, b->stream));
     dim3 block(64, 4, 1), grid(b->max_blocks, 1, b->total_slices);
-    // bricks when every object's rows divide into them (first volume on variant 11: workgroup patches, round-2a shape)
+    // a class per wavefront brick (every member has a brick view: dim_x % 4 == 0 is a condition of tsdf_batch_create)
     int brick_blocks = 0;
-    bool bricks = classify && b->vols[0]->variant != 11;
+    bool bricks = classify && !(kExperiments && b->vols[0]->variant == 11);
     for (int i = 0; i < n && bricks; ++i) {
         const tsdfk::IntegrateParams &q = b->h_params[s][i];
         bricks = q.brick_q > 0;
@@ -2399,15 +2263,17 @@ int tsdf_batch_integrate_device(tsdf_batch *b, const float *depth_dev, const uin
                            b->d_params[s], b->d_poses[s], b->d_group_map, b->d_brick_class, brick_blocks, b->total_groups);
         hipLaunchKernelGGL((tsdfk::integrate_multi_batched_bricks<true>), dim3(brick_blocks, 1, b->total_groups), block, 0, b->stream,
                            b->d_params[s], b->d_poses[s], b->d_group_map, b->d_brick_class);
-    } else if (classify) {
+#ifdef TSDF_EXPERIMENTS
+    } else if (classify) {   // variant 11: a class per 1024-voxel workgroup patch (round 2a's shape)
         const size_t n_wg = (size_t)b->max_blocks * b->total_slices;
         hipLaunchKernelGGL(tsdfk::classify_workgroups_batched, dim3((unsigned)((n_wg + 255) / 256)), dim3(256), 0, b->stream,
                            b->d_params[s], b->d_poses[s], b->d_slice_map, b->d_wg_class, b->max_blocks, b->total_slices);
-        hipLaunchKernelGGL((tsdfk::integrate_multi_batched<true, true>), grid, block, 0, b->stream, b->d_params[s], b->d_poses[s],
+        hipLaunchKernelGGL((tsdfk::integrate_multi_batched_cls<true, true>), grid, block, 0, b->stream, b->d_params[s], b->d_poses[s],
                            b->d_slice_map, b->d_wg_class);
+#endif
     } else {
-        hipLaunchKernelGGL((tsdfk::integrate_multi_batched<true, false>), grid, block, 0, b->stream, b->d_params[s], b->d_poses[s],
-                           b->d_slice_map, (const uint8_t *)nullptr);
+        hipLaunchKernelGGL((tsdfk::integrate_multi_batched<true>), grid, block, 0, b->stream, b->d_params[s], b->d_poses[s],
+                           b->d_slice_map);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(b->slot_done[s], b->stream));

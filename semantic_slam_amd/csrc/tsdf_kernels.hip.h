@@ -135,74 +135,42 @@ __device__ __forceinline__ bool voxel_dist(const IntegrateParams &p, const RowTe
 }
 
 // ------------------------------------------------------------------------------------------
-// integrate_rows<VX>: block = 64 x 4 threads; a wavefront = 64 lanes x VX voxels of one row.
-// grid = (ceil(xgroups/64), ceil(dim_y/4), nz).
-// VX = 4 needs dim_x % 4 == 0 (rows stay 16-byte aligned); VX = 1 takes any dim_x.
+// integrate_scalar: the any-dim_x fallback (rows that are not 16-byte aligned: dim_x % 4 != 0).  One voxel per lane,
+// block = 64 x 4 threads, grid = (ceil(dim_x / 64), ceil(dim_y / 4), nz); statement for statement the reference's update.
 // ------------------------------------------------------------------------------------------
-template <int VX, bool MASKED>
-__global__ __launch_bounds__(256) void integrate_rows(IntegrateParams p)
+template <bool MASKED>
+__global__ __launch_bounds__(256) void integrate_scalar(IntegrateParams p)
 {
-    const int xg = blockIdx.x * 64 + threadIdx.x;
+    const int gx = blockIdx.x * 64 + threadIdx.x;
     const int gy = blockIdx.y * 4 + threadIdx.y;
     const int lz = blockIdx.z;
-    if (xg >= p.xgroups || gy >= p.dim_y) return;
+    if (gx >= p.dim_x || gy >= p.dim_y) return;
     const int gz = p.z_begin + lz;  // GLOBAL z: a slab must round exactly like the whole grid
-
     const RowTerms r = row_terms(p, gy, gz);
-
-    float dist[VX];
-    bool upd[VX];
-    bool any = false;
-#pragma unroll
-    for (int j = 0; j < VX; ++j) {
-        upd[j] = voxel_dist<MASKED>(p, r, xg * VX + j, dist[j]);
-        any |= upd[j];
-    }
-    // wavefront early-out: nothing to update in these 64*VX voxels -> no volume traffic at all
-    if (__ballot(any) == 0ull) return;
-    if (!any) return;
-
-    const size_t row = ((size_t)lz * p.dim_y + gy) * (size_t)p.dim_x + (size_t)xg * VX;
-    if constexpr (VX == 4) {
-        float4 t = *reinterpret_cast<const float4 *>(p.tsdf + row);
-        float4 w = *reinterpret_cast<const float4 *>(p.weight + row);
-        float tv[4] = {t.x, t.y, t.z, t.w};
-        float wv[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (upd[j]) {  // ref: src/tsdf.cu:54-57
-                float w_new = wv[j] + 1.0f;
-                tv[j] = (tv[j] * wv[j] + dist[j]) / w_new;
-                wv[j] = w_new;
-            }
-        }
-        *reinterpret_cast<float4 *>(p.tsdf + row) = make_float4(tv[0], tv[1], tv[2], tv[3]);
-        *reinterpret_cast<float4 *>(p.weight + row) = make_float4(wv[0], wv[1], wv[2], wv[3]);
-    } else {
-#pragma unroll
-        for (int j = 0; j < VX; ++j) {
-            if (upd[j]) {
-                float w_old = p.weight[row + j];
-                float w_new = w_old + 1.0f;
-                p.weight[row + j] = w_new;
-                p.tsdf[row + j] = (p.tsdf[row + j] * w_old + dist[j]) / w_new;
-            }
-        }
-    }
+    float dist;
+    const bool upd = voxel_dist<MASKED>(p, r, gx, dist);
+    // wavefront early-out: nothing to update in these 64 voxels -> no volume traffic at all
+    if (__ballot(upd) == 0ull) return;
+    if (!upd) return;
+    const size_t at = ((size_t)lz * p.dim_y + gy) * (size_t)p.dim_x + (size_t)gx;
+    const float w_old = p.weight[at];     // ref: src/tsdf.cu:54-57
+    const float w_new = w_old + 1.0f;
+    p.weight[at] = w_new;
+    p.tsdf[at] = (p.tsdf[at] * w_old + dist) / w_new;
 }
 
 // ------------------------------------------------------------------------------------------
-// integrate_tile<R, ELIDE, NT, MASKED, SUM, EARLY>: the tuned kernel.
+// integrate_tile<R, MASKED>: the one-frame kernel (one launch per tsdf_integrate* call).
 //
 // block = 64 x 4 threads; a lane owns a 4(x) x R(y) patch of one z slice, a wavefront
-// 256(x) x R(y).  grid = (ceil(xgroups/64), ceil(dim_y/(4R)), nz).  Needs dim_x % 4 == 0.
+// 256(x) x R(y).  grid = (ceil(xgroups/64), ceil(dim_y/(4R)), nz).  Needs dim_x % 256 == 0 (rows that are not take
+// the flat mapping, tsdf_multiframe.hip.h).
 //
 //  * the x-only products (rx0*dx, ry0*dx, rz0*dx) are computed once and shared by the R rows;
 //  * geometry is branch-free (rejected voxels read pixel 0): all 4R depth samples of a lane are
 //    gathered back to back;
-//  * a wavefront with nothing to update never writes, and (without EARLY, or when the coarse
-//    frustum test rejects its patch) never reads the volume either (__ballot early-out);
-//  * ELIDE: arithmetic whose result is known exactly is skipped per wavefront --
+//  * a wavefront with nothing to update neither reads nor writes the volume (__ballot early-out);
+//  * exact elisions: arithmetic whose result is known exactly is skipped per wavefront --
 //      - diff >= trunc  =>  fmin(1, diff/trunc) == 1: no division unless some lane is inside
 //        the truncation band (correctly rounded a/b >= 1 whenever a >= b > 0);
 //      - tsdf*w + dist == w + 1 (free space: tsdf 1, dist 1)  =>  the quotient is exactly 1:
@@ -210,21 +178,16 @@ __global__ __launch_bounds__(256) void integrate_rows(IntegrateParams p)
 //      - a row whose TSDF values all come out bit-identical to what was loaded is not stored
 //        (the weight always changes and is always stored).
 //    Every skipped value is the value the full computation would produce, bit for bit.
-//  * NT: volume loads/stores carry the non-temporal hint (each byte is touched once per frame).
-//  * SUM: free-space summary.  A wavefront's row is one 256-voxel segment with one flag word;
+//  * volume loads/stores carry the non-temporal hint (each byte is touched once per frame).
+//  * free-space summary.  A wavefront's row is one 256-voxel segment with one flag word;
 //    while the flag says "all TSDF == 1" the TSDF quad is not loaded -- the constant 1 stands
 //    in for it and the same arithmetic runs on it -- so free space moves 8 B per voxel, not 12.
 //    The first update that leaves a value != 1 stores the row and clears the flag; flags are
 //    only ever set by fill_grid / recompute_flags (create, reset, upload).
-//  * EARLY: the kernel was limited by bytes in flight, not by bandwidth or VALU: a wavefront
-//    issued its volume loads only after ~1000 cycles of geometry plus a depth-gather round
-//    trip.  With EARLY the flag words and the weight quads (and, once the flags are back, the
-//    TSDF quads of rows that are not all-ones) are requested at the top of the kernel and
-//    arrive while the geometry runs.  The loads are speculative -- a patch may turn out to need
-//    nothing -- so they are gated by a coarse, wave-uniform test of the patch's four corners
-//    against the image; the gate only decides WHEN a quad is loaded, never what is computed
-//    (a lane that has to update a quad that was not pre-loaded loads it then), so it needs no
-//    rounding analysis.
+//  * exact shared-reciprocal projection and one-instruction pixel rounding (below).
+// The earlier stages of this ladder (no elision, no summary, R = 1 / 4, speculative volume loads, depth tiles staged in
+// LDS) are measurement builds: tsdf_experiments.hip.h, -DTSDF_EXPERIMENTS.
+// ------------------------------------------------------------------------------------------
 // ------------------------------------------------------------------------------------------
 // ------------------------------------------------------------------------------------------
 // Exact division, cheaper.  hipcc lowers an IEEE fp32 `n / d` to
@@ -335,124 +298,25 @@ __device__ __forceinline__ int pixel_index24(int iv, int W, int iu)
     return (int)(__umul24((unsigned)iv, (unsigned)W) + (unsigned)iu);
 }
 
-// Coarse frustum gate for the speculative loads: true unless the patch's four corners
-// (x0|x1, y0|y1 at slice gz) are all behind the camera or all beyond the same image edge by
-// more than one pixel.  Lanes 0..3 each project one corner; approximate arithmetic is fine.
-__device__ __forceinline__ bool patch_may_be_visible(const IntegrateParams &p, int x0, int x1, int y0,
-                                                     int y1, int gz)
-{
-    const int lane = threadIdx.x & 63;
-    const float bx = p.ox + (float)((lane & 1) ? x1 : x0) * p.vs - p.tx;
-    const float by = p.oy + (float)((lane & 2) ? y1 : y0) * p.vs - p.ty;
-    const float bz = p.oz + (float)gz * p.vs - p.tz;
-    const float cx = p.rx0 * bx + p.rx1 * by + p.rx2 * bz;
-    const float cy = p.ry0 * bx + p.ry1 * by + p.ry2 * bz;
-    const float cz = p.rz0 * bx + p.rz1 * by + p.rz2 * bz;
-    const float inv = __builtin_amdgcn_rcpf(cz);
-    const float u = p.fx * (cx * inv) + p.cx;
-    const float v = p.fy * (cy * inv) + p.cy;
-    const bool corner = lane < 4;
-    const bool front = cz > 0.0f;
-    const unsigned long long m = __ballot(corner);
-    const bool all_front = (__ballot(corner && front) == m);
-    if (__ballot(corner && !front) == m) return false;          // wholly behind the camera
-    if (!all_front) return true;                                 // straddles the camera plane: no claim
-    if (__ballot(corner && u < -1.0f) == m) return false;
-    if (__ballot(corner && u > (float)p.W) == m) return false;
-    if (__ballot(corner && v < -1.0f) == m) return false;
-    if (__ballot(corner && v > (float)p.H) == m) return false;
-    return true;
-}
-
-// MASKED: 0 = plain depth, 1 = depth * (mask/255) (p.mask must be set), 2 = decided per launch
-// parameter block (p.mask may be null) -- the batched kernel, where each object brings its own.
-// LDSD: stage the depth pixels the workgroup's voxel patch projects onto in LDS and sample from there
-// (the north-star sketch).  Kept as a measured experiment: the frame lives in every XCD's L2 and the
-// kernel is VALU-issue-bound, so the extra bounding-box / index arithmetic costs more than the L1/L2
-// gathers it replaces.
-constexpr int kLdsTile = 4096;   // floats: 16 KiB per workgroup, 8+ workgroups per CU still fit
-
-template <int R, bool ELIDE, bool NT, int MASKED, bool SUM, bool EARLY, bool FAST, bool LDSD = false>
+// MASKED: 0 = plain depth, 1 = depth * (mask/255) (p.mask must be set).
+template <int R, int MASKED>
 __device__ __forceinline__ void integrate_tile_body(const IntegrateParams &p, const int bx, const int by, const int lz)
 {
     const int gz = p.z_begin + lz;
-    // ---- (LDSD) depth tile of the workgroup's 256 x 4R voxel patch -------------------------------
-    __shared__ float lds_depth[LDSD ? kLdsTile : 1];
-    int tu0 = 0, tv0 = 0, tw = 0, th = 0;   // tile origin and size in pixels (workgroup-uniform); tw = 0: no tile
-    if constexpr (LDSD) {
-        const int lane = threadIdx.x & 63;
-        const int x0 = bx * 256, x1 = min(x0 + 255, p.dim_x - 1);
-        const int y0 = by * 4 * R, y1 = min(y0 + 4 * R - 1, p.dim_y - 1);
-        // lanes 0..3 project the four corners (approximate arithmetic: the tile only has to CONTAIN the
-        // exact pixels; a voxel whose exact pixel falls outside it reads global memory instead)
-        const float qx = p.ox + (float)((lane & 1) ? x1 : x0) * p.vs - p.tx;
-        const float qy = p.oy + (float)((lane & 2) ? y1 : y0) * p.vs - p.ty;
-        const float qz = p.oz + (float)gz * p.vs - p.tz;
-        const float ccx = p.rx0 * qx + p.rx1 * qy + p.rx2 * qz;
-        const float ccy = p.ry0 * qx + p.ry1 * qy + p.ry2 * qz;
-        const float ccz = p.rz0 * qx + p.rz1 * qy + p.rz2 * qz;
-        const float inv = __builtin_amdgcn_rcpf(ccz);
-        float u = p.fx * (ccx * inv) + p.cx, v = p.fy * (ccy * inv) + p.cy;
-        float umin = u, umax = u, vmin = v, vmax = v, zmin = ccz;
-#pragma unroll
-        for (int m = 1; m <= 2; m <<= 1) {
-            umin = fminf(umin, __shfl_xor(umin, m)); umax = fmaxf(umax, __shfl_xor(umax, m));
-            vmin = fminf(vmin, __shfl_xor(vmin, m)); vmax = fmaxf(vmax, __shfl_xor(vmax, m));
-            zmin = fminf(zmin, __shfl_xor(zmin, m));
-        }
-        umin = __shfl(umin, 0); umax = __shfl(umax, 0); vmin = __shfl(vmin, 0); vmax = __shfl(vmax, 0);
-        zmin = __shfl(zmin, 0);
-        // all corners in front of the camera and a sane box -> clip to the image, 2-pixel safety border
-        if (zmin > 0.0f && umax - umin < 4096.0f && vmax - vmin < 4096.0f && umin > -1.0e6f && vmin > -1.0e6f &&
-            umax < 1.0e6f && vmax < 1.0e6f) {
-            const int a0 = max(0, (int)floorf(umin) - 2), a1 = min(p.W - 1, (int)ceilf(umax) + 2);
-            const int b0 = max(0, (int)floorf(vmin) - 2), b1 = min(p.H - 1, (int)ceilf(vmax) + 2);
-            const int w_ = a1 - a0 + 1, h_ = b1 - b0 + 1;
-            if (w_ > 0 && h_ > 0 && w_ * h_ <= kLdsTile) { tu0 = a0; tv0 = b0; tw = w_; th = h_; }
-        }
-        for (int ty = threadIdx.y; ty < th; ty += 4)
-            for (int tx = lane; tx < tw; tx += 64)
-                lds_depth[ty * tw + tx] = p.depth[(size_t)(tv0 + ty) * p.W + (tu0 + tx)];
-        __syncthreads();
-    }
     const int xg = bx * 64 + threadIdx.x;
     const int gy0 = (by * 4 + threadIdx.y) * R;
     if (xg >= p.xgroups || gy0 >= p.dim_y) return;
     const size_t row0 = ((size_t)lz * p.dim_y + gy0) * (size_t)p.dim_x + (size_t)xg * 4;
     const size_t flag0 = ((size_t)lz * p.dim_y + gy0) * (size_t)p.nseg + bx;
 
-    // ---- phase 0: summary flags, and (EARLY) the speculative volume loads -----------------------
+    // ---- phase 0: summary flags ------------------------------------------------------------------
     uint32_t fl[R];
     float4 t4[R], w4[R];
-    bool have_w[R], have_t[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        fl[r] = 0u;
-        if (SUM && gy0 + r < p.dim_y) fl[r] = p.flags[flag0 + (size_t)r * p.nseg];
+        fl[r] = gy0 + r < p.dim_y ? p.flags[flag0 + (size_t)r * p.nseg] : 0u;
         t4[r] = make_float4(1.f, 1.f, 1.f, 1.f);
         w4[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-        have_w[r] = have_t[r] = false;
-    }
-    if (EARLY) {
-        const int x_first = bx * 256;
-        const int x_last = min(x_first + 255, p.dim_x - 1);
-        const int y_last = min(gy0 + R - 1, p.dim_y - 1);
-        if (patch_may_be_visible(p, x_first, x_last, gy0, y_last, gz)) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                if (gy0 + r < p.dim_y) {
-                    w4[r] = vol_load<NT>(p.weight + row0 + (size_t)r * p.dim_x);
-                    have_w[r] = true;
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                if (gy0 + r < p.dim_y && !(SUM && (fl[r] & 1u))) {
-                    t4[r] = vol_load<NT>(p.tsdf + row0 + (size_t)r * p.dim_x);
-                    have_t[r] = true;
-                }
-            }
-        }
     }
 
     // x-only and z-only terms (ref: src/tsdf.cu:27,29,33,35-38)
@@ -471,7 +335,6 @@ __device__ __forceinline__ void integrate_tile_body(const IntegrateParams &p, co
     float pcz[R][4], dval[R][4];
     bool geo[R][4];
     int pixel[R][4];
-    int pix_u[LDSD ? R : 1][4], pix_v[LDSD ? R : 1][4];   // (LDSD) the pixel as column / row
     // camera-frame z of every voxel first: it decides which projection path the wavefront takes
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -487,7 +350,7 @@ __device__ __forceinline__ void integrate_tile_body(const IntegrateParams &p, co
     const float cmin = fminf(fminf(pcz[0][0], pcz[0][3]), fminf(pcz[R - 1][0], pcz[R - 1][3]));
     const float cmax = fmaxf(fmaxf(pcz[0][0], pcz[0][3]), fmaxf(pcz[R - 1][0], pcz[R - 1][3]));
     const bool unsafe = !(cmin > p.cz_margin) & !(cmax < -p.cz_margin);
-    const bool fast = FAST && p.fast_ok != 0 && __ballot(unsafe) == 0ull;   // wave-uniform
+    const bool fast = p.fast_ok != 0 && __ballot(unsafe) == 0ull;   // wave-uniform
     if (fast) {
         // Same values as the generic branch below, obtained with fewer instructions:
         //  - both quotients of a voxel from one refined reciprocal (fast_div2), packed;
@@ -515,7 +378,6 @@ __device__ __forceinline__ void integrate_tile_body(const IntegrateParams &p, co
                                 ((unsigned)iu < (unsigned)p.W) & ((unsigned)iv < (unsigned)p.H);
                 geo[r][j] = ok;
                 pixel[r][j] = ok ? pixel_index24(iv, p.W, iu) : 0;
-                if constexpr (LDSD) { pix_u[r][j] = ok ? iu : 0; pix_v[r][j] = ok ? iv : 0; }
             }
         }
     } else {
@@ -539,7 +401,6 @@ __device__ __forceinline__ void integrate_tile_body(const IntegrateParams &p, co
                                 pv < (float)p.H;
                 geo[r][j] = ok;
                 pixel[r][j] = ok ? (int)pv * p.W + (int)pu : 0;
-                if constexpr (LDSD) { pix_u[r][j] = ok ? (int)pu : 0; pix_v[r][j] = ok ? (int)pv : 0; }
             }
         }
     }
@@ -549,16 +410,8 @@ __device__ __forceinline__ void integrate_tile_body(const IntegrateParams &p, co
         for (int j = 0; j < 4; ++j) {
             // unsigned 32-bit offset from a wave-uniform base: the load takes the base from SGPRs
             const uint32_t px = (uint32_t)pixel[r][j];
-            float d;
-            if constexpr (LDSD) {
-                const uint32_t du = (uint32_t)(pix_u[r][j] - tu0), dv = (uint32_t)(pix_v[r][j] - tv0);
-                if (du < (uint32_t)tw && dv < (uint32_t)th) d = lds_depth[dv * tw + du];
-                else d = gather_f32(p.depth, px);   // outside the staged tile (or no tile): the exact pixel from memory
-            } else {
-                d = gather_f32(p.depth, px);
-            }
-            if (MASKED == 1 || (MASKED == 2 && p.mask != nullptr))
-                d = d * (p.mask[px] >= 128 ? 1.0f : 0.0f);  // ref: src/Engine.cpp:192-193
+            float d = gather_f32(p.depth, px);
+            if (MASKED == 1) d = d * (p.mask[px] >= 128 ? 1.0f : 0.0f);  // ref: src/Engine.cpp:192-193
             dval[r][j] = d;
         }
     }
@@ -585,19 +438,19 @@ __device__ __forceinline__ void integrate_tile_body(const IntegrateParams &p, co
         band |= bandr[r];
         any |= rowany[r];
     }
-    if (__ballot(any) == 0ull) return;  // wavefront early-out: nothing is written
+    if (__ballot(any) == 0ull) return;  // wavefront early-out: nothing is read or written
     if (!any) return;
 
-    // ---- phase 3: whatever was not pre-loaded; truncated distance -------------------------------
+    // ---- phase 3: the volume quads; truncated distance -----------------------------------------
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         if (rowany[r]) {
-            if (!have_w[r]) w4[r] = vol_load<NT>(p.weight + row0 + (size_t)r * p.dim_x);
-            if (!have_t[r] && !(SUM && (fl[r] & 1u))) t4[r] = vol_load<NT>(p.tsdf + row0 + (size_t)r * p.dim_x);
+            w4[r] = vol_load<true>(p.weight + row0 + (size_t)r * p.dim_x);
+            if (!(fl[r] & 1u)) t4[r] = vol_load<true>(p.tsdf + row0 + (size_t)r * p.dim_x);
         }
     }
     float dist[R][4];
-    if (!ELIDE || __ballot(band) != 0ull) {
+    if (__ballot(band) != 0ull) {
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -612,15 +465,15 @@ __device__ __forceinline__ void integrate_tile_body(const IntegrateParams &p, co
     // ---- phase 4: running weighted mean (ref: src/tsdf.cu:54-57), stores ----------------------
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        if (SUM && fl[r] == 3u && __ballot(bandr[r]) == 0ull) {
+        if (fl[r] == 3u && __ballot(bandr[r]) == 0ull) {
             // Free space, wave-uniform: every TSDF value of the segment is 1, every weight is finite
             // and >= 0, and every updated lane has dist == 1.  Then num = fl(1*w + 1) = fl(w + 1) = wn,
             // the quotient is exactly 1, the TSDF row is unchanged: only the weights move.
             if (rowany[r]) {
                 const float4 w = w4[r];
-                vol_store<NT>(p.weight + row0 + (size_t)r * p.dim_x,
-                              make_float4(upd[r][0] ? w.x + 1.0f : w.x, upd[r][1] ? w.y + 1.0f : w.y,
-                                          upd[r][2] ? w.z + 1.0f : w.z, upd[r][3] ? w.w + 1.0f : w.w));
+                vol_store<true>(p.weight + row0 + (size_t)r * p.dim_x,
+                                make_float4(upd[r][0] ? w.x + 1.0f : w.x, upd[r][1] ? w.y + 1.0f : w.y,
+                                            upd[r][2] ? w.z + 1.0f : w.z, upd[r][3] ? w.w + 1.0f : w.w));
             }
             continue;
         }
@@ -636,7 +489,7 @@ __device__ __forceinline__ void integrate_tile_body(const IntegrateParams &p, co
             need |= upd[r][j] && !(num[j] == wn[j] && wn[j] < 3.0e38f && wn[j] > 0.0f);
         }
         float nt[4];
-        if (!ELIDE || __ballot(rowany[r] && need) != 0ull) {
+        if (__ballot(rowany[r] && need) != 0ull) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) nt[j] = num[j] / wn[j];
         } else {
@@ -652,28 +505,21 @@ __device__ __forceinline__ void integrate_tile_body(const IntegrateParams &p, co
             tv[j] = newt;
             wv[j] = upd[r][j] ? wn[j] : wv[j];
         }
-        if (SUM && (fl[r] & 1u) && __ballot(notone) != 0ull) {
+        if ((fl[r] & 1u) && __ballot(notone) != 0ull) {
             if (notone) p.flags[flag0 + (size_t)r * p.nseg] = fl[r] & 2u;  // segment no longer all ones
         }
-        const bool store_t = !ELIDE || __ballot(rowany[r] && changed) != 0ull;
+        const bool store_t = __ballot(rowany[r] && changed) != 0ull;
         if (rowany[r]) {
-            if (store_t) vol_store<NT>(p.tsdf + row0 + (size_t)r * p.dim_x, make_float4(tv[0], tv[1], tv[2], tv[3]));
-            vol_store<NT>(p.weight + row0 + (size_t)r * p.dim_x, make_float4(wv[0], wv[1], wv[2], wv[3]));
+            if (store_t) vol_store<true>(p.tsdf + row0 + (size_t)r * p.dim_x, make_float4(tv[0], tv[1], tv[2], tv[3]));
+            vol_store<true>(p.weight + row0 + (size_t)r * p.dim_x, make_float4(wv[0], wv[1], wv[2], wv[3]));
         }
     }
 }
 
-// CLS: the launch comes with a workgroup class table (IntegrateParams::wg_class); a workgroup whose whole patch
-// the depth tile table proved untouched by this frame leaves at once (masked per-object volumes: most of them).
-template <int R, bool ELIDE, bool NT, bool MASKED, bool SUM = false, bool EARLY = false, bool FAST = false,
-          bool LDSD = false, bool CLS = false>
+template <int R, bool MASKED>
 __global__ __launch_bounds__(256) void integrate_tile(IntegrateParams p)
 {
-    if constexpr (CLS) {
-        const unsigned id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        if (p.wg_class[id] == 2) return;   // wave-uniform (scalar load): nothing to update anywhere in the patch
-    }
-    integrate_tile_body<R, ELIDE, NT, MASKED ? 1 : 0, SUM, EARLY, FAST, LDSD>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+    integrate_tile_body<R, MASKED ? 1 : 0>(p, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Device self-test of fast_div2 against the compiler's IEEE division: pseudo-random operands from a

@@ -414,56 +414,6 @@ __device__ __forceinline__ int classify_patch(const IntegrateParams &p, const Cl
     return 0;
 }
 
-// One-frame launches: the class of every workgroup's patch, one THREAD per workgroup, ahead of the Integrate launch
-// (a 200^3 volume has 7 813 workgroups: this kernel is noise).  The Integrate kernel then reads one byte per
-// workgroup through a scalar load.  rows_per_wg > 0: row mapping (256 x rows_per_wg voxels per workgroup, grid =
-// (x blocks, y blocks, slices)); rows_per_wg == 0: flat mapping (1024 consecutive voxels, grid = (blocks, 1, slices)).
-__device__ __forceinline__ int classify_wg_patch(const IntegrateParams &p, const FramePose *pose, int bx, int by, int lz,
-                                                 int rows_per_wg)
-{
-    int xa, xb, ya, yb;
-    if (rows_per_wg == 0) {
-        const int n_vox = p.quads_per_slice * 4;
-        const int i0 = bx * 1024;
-        if (i0 >= n_vox) return 2;                       // a block past the end of the slice: nothing there
-        const int i1 = min(i0 + 1023, n_vox - 1);
-        ya = i0 / p.dim_x;
-        yb = i1 / p.dim_x;
-        xa = ya == yb ? i0 - ya * p.dim_x : 0;
-        xb = ya == yb ? i1 - yb * p.dim_x : p.dim_x - 1;
-    } else {
-        xa = bx * 256;
-        ya = by * rows_per_wg;
-        if (xa >= p.dim_x || ya >= p.dim_y) return 2;
-        xb = min(xa + 255, p.dim_x - 1);
-        yb = min(ya + rows_per_wg - 1, p.dim_y - 1);
-    }
-    return classify_patch(p, class_pose(*pose), xa, xb, ya, yb, p.z_begin + lz);
-}
-
-__global__ __launch_bounds__(256) void classify_workgroups(IntegrateParams p, FramePose pose, uint8_t *cls, int nbx, int nby,
-                                                           int nz, int rows_per_wg)
-{
-    const int id = blockIdx.x * 256 + threadIdx.x;
-    if (id >= nbx * nby * nz) return;
-    const int bx = id % nbx, t = id / nbx;
-    cls[id] = (uint8_t)classify_wg_patch(p, &pose, bx, t % nby, t / nby, rows_per_wg);
-}
-
-// the batched form: slice_map[z] = {object, slice}; params / poses per object; flat mapping; grid (max_blocks, 1, total_slices)
-__global__ __launch_bounds__(256) void classify_workgroups_batched(const IntegrateParams *__restrict__ params,
-                                                                   const FramePose *__restrict__ poses,
-                                                                   const int2 *__restrict__ slice_map, uint8_t *cls,
-                                                                   int max_blocks, int total_slices)
-{
-    const int id = blockIdx.x * 256 + threadIdx.x;
-    if (id >= max_blocks * total_slices) return;
-    const int bx = id % max_blocks, z = id / max_blocks;
-    const int2 m = slice_map[z];
-    const IntegrateParams p = params[m.x];
-    cls[id] = (uint8_t)classify_wg_patch(p, poses + m.x, bx, 0, m.y, 0);
-}
-
 // One masked frame into one volume, with bricks: the class of every wavefront brick, one thread per brick; index =
 // (slice group * blocks + workgroup) * 4 + wavefront, blocks = workgroups per slice group (brick_s slices each).
 __global__ __launch_bounds__(256) void classify_bricks(IntegrateParams p, FramePose pose, uint8_t *cls, int blocks, int nzg)
@@ -515,12 +465,6 @@ struct LabelState {
     float prob_thd;
 };
 
-struct MultiParams {
-    IntegrateParams common;   // grid, intrinsics, volume pointers, summary; its pose fields are unused
-    const FramePose *frames;  // n_frames blocks in device memory (indexed in a loop: a by-value array
-    int n_frames;             // in the kernarg would be copied to registers and selected per frame)
-};
-
 // The same with the frame blocks inside the kernarg itself: nothing to stage in device memory before the
 // launch (a 4 us copy on the stream per launch -- 1 % of a 512^3 pass, 8 % of a 200^3 one).  The kernel
 // reads them through the kernarg segment pointer with the loop's wave-uniform index (scalar loads),
@@ -537,11 +481,13 @@ struct MultiParamsInline {
     // index, so with a slice count that is a multiple of 8 order 1 gives every slice to ONE XCD -- and a surface that
     // lies across few slices (a wall facing the camera) then keeps one or two XCDs busy while the others idle
     int z_fastest;
-    // BRICK launches: per super-brick (a workgroup's four bricks x kSuperZ consecutive slice groups) the frames that may
-    // do something to it (classify_superbricks); a workgroup whose word is 0 leaves before it stages or classifies
+#ifdef TSDF_EXPERIMENTS
+    // (integrate_multi_wg) per super-brick (a workgroup's four bricks x kSuperZ consecutive slice groups) the frames that
+    // may do something to it (classify_superbricks); a workgroup whose word is 0 leaves before it stages or classifies
     // anything.  Null: no such table.  Index = workgroup index within the slice group * nz_super + slice group / kSuperZ.
     const unsigned int *super_mask;
     int nz_super;
+#endif
 };
 
 constexpr int kSuperZ = 4;
@@ -961,159 +907,26 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
     }
 }
 
-template <int R, bool NT, bool FLAT>
-__global__ __launch_bounds__(256, R == 2 ? 6 : 1) void integrate_multi(MultiParams mp)
-{
-    multi_body<R, NT, FLAT>(mp.common, mp.frames, mp.n_frames, blockIdx.x, blockIdx.y, blockIdx.z);
-}
-
 #ifndef TSDF_BRICK_WAVES
 #define TSDF_BRICK_WAVES 8   /* waves per SIMD asked of the brick instantiation (A/B builds override it) */
 #endif
-template <int R, bool NT, bool FLAT, bool LABELS = false, bool MASKS = true, bool SHORT = false, bool BRICK = false>
-__global__ __launch_bounds__(256, R == 2 ? 6 : (BRICK ? (LABELS ? 6 : TSDF_BRICK_WAVES) : 1)) void integrate_multi_inline(MultiParamsInline mp)
+// The per-voxel fused launch: up to 32 frames per pass, frame blocks read from the kernarg.  (The classified launches run over
+// the brick work list: classify_brick_list / integrate_brick_list below.)
+template <int R, bool NT, bool FLAT, bool LABELS = false, bool MASKS = true>
+__global__ __launch_bounds__(256, R == 2 ? 6 : 1) void integrate_multi_inline(MultiParamsInline mp)
 {
-    static_assert(!BRICK || SHORT, "the brick mapping exists for the classification's sake");
     // the single by-value parameter starts the kernarg segment (offset 0)
     typedef const char __attribute__((address_space(4))) *kernarg_ptr;
     kernarg_ptr base = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
     typedef const FramePose __attribute__((address_space(4))) *frames_ptr;
     frames_ptr frames = (frames_ptr)(base + offsetof(MultiParamsInline, frames));
-    unsigned int free_frames = 0u, skip_frames = 0u;
     const int wg_x = mp.z_fastest ? (int)blockIdx.z : (int)blockIdx.x, wg_y = (int)blockIdx.y;
     int wg_z = mp.z_fastest ? (int)blockIdx.x : (int)blockIdx.z;
     if (mp.z_fastest == 2) {
         wg_z += (int)((unsigned)(wg_x + wg_y) % gridDim.x);
         if (wg_z >= (int)gridDim.x) wg_z -= (int)gridDim.x;
     }
-    if constexpr (BRICK) {
-        if (mp.super_mask != nullptr && mp.super_mask[(size_t)wg_x * mp.nz_super + wg_z / kSuperZ] == 0u) {
-            // every frame skips the whole super-brick: the workgroup's wavefront-frames are all "skipped" claims
-            const IntegrateParams &p = mp.common;
-            if ((p.claim_counter != nullptr || p.shortcut_stats != nullptr) && threadIdx.x == 0 && threadIdx.y == 0) {
-                const int in_range = max(0, min(4, p.brick_groups * p.bricks_per_group - wg_x * 4));
-                if (p.claim_counter != nullptr) atomicAdd(p.claim_counter, (unsigned long long)(in_range * mp.n_frames));
-                if (p.shortcut_stats != nullptr) atomicAdd(p.shortcut_stats + 2, (unsigned)(in_range * mp.n_frames));
-            }
-            return;
-        }
-    }
-    if constexpr (SHORT) {
-        // Patch classification in the prologue.  The first wavefront stages the frame blocks in LDS (coalesced); then
-        //   row / flat mapping: it classifies the workgroup's patch (256 x 4 voxels, or 1024 consecutive ones), one frame
-        //     per lane, and bit f of two words in LDS tells every wavefront what frame f does to all of its voxels;
-        //   BRICK: every wavefront classifies its own brick, one frame per lane, and keeps the two words itself.
-        __shared__ FramePose s_frames[kMaxFramesPerLaunch];
-        __shared__ unsigned int s_bits[2];
-        __shared__ unsigned int s_claims[2];   // BRICK: (free, skipped) wavefront-frames of the workgroup, and
-        __shared__ unsigned int s_done;        //        how many of its wavefronts have added theirs
-        static_assert(sizeof(FramePose) % 8 == 0, "staged as 8-byte words");
-        const IntegrateParams &p = mp.common;
-        const int lane = threadIdx.x;
-        if (threadIdx.y == 0) {
-            constexpr int kWords = (int)(sizeof(FramePose) * kMaxFramesPerLaunch / 8);
-            const unsigned long long __attribute__((address_space(4))) *src =
-                (const unsigned long long __attribute__((address_space(4))) *)frames;
-            unsigned long long *dst = reinterpret_cast<unsigned long long *>(s_frames);
-            for (int k = lane; k < kWords; k += 64) dst[k] = src[k];
-            if constexpr (BRICK) { if (lane == 0) { s_claims[0] = 0u; s_claims[1] = 0u; s_done = 0u; } }
-            if constexpr (!BRICK) {
-                int xa, xb, ya, yb;
-                if constexpr (FLAT) {
-                    const int i0 = wg_x * 1024;
-                    const int i1 = min(i0 + 1023, p.quads_per_slice * 4 - 1);
-                    ya = i0 / p.dim_x;
-                    yb = i1 / p.dim_x;
-                    xa = ya == yb ? i0 - ya * p.dim_x : 0;
-                    xb = ya == yb ? i1 - yb * p.dim_x : p.dim_x - 1;
-                } else {
-                    xa = wg_x * 256;
-                    xb = min(xa + 255, p.dim_x - 1);
-                    ya = wg_y * 4;
-                    yb = min(ya + 3, p.dim_y - 1);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                int cls = 0;
-                if (lane < mp.n_frames) cls = classify_patch(p, class_pose(s_frames[lane]), xa, xb, ya, yb, p.z_begin + wg_z);
-                const unsigned long long fb = __ballot(cls == 1), sb = __ballot(cls == 2);
-                if (lane == 0) {
-                    s_bits[0] = (unsigned int)fb;
-                    s_bits[1] = (unsigned int)sb;
-                    if (p.claim_counter != nullptr && (fb | sb) != 0ull)
-                        atomicAdd(p.claim_counter, ((unsigned long long)__popcll(fb) << 32) | (unsigned long long)__popcll(sb));
-                }
-            }
-        }
-        __syncthreads();
-        if constexpr (BRICK) {
-            const int brick = wg_x * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.y);
-            const int g = brick / p.bricks_per_group, i = brick - g * p.bricks_per_group;
-            const int xa = i * p.brick_q * 4, ya = g * p.brick_r;
-            const int z0 = wg_z * p.brick_s, z1 = min(z0 + p.brick_s - 1, p.nz - 1);
-            // frame = lane mod 32; the half-waves share the box's near and far slice (classify_patch<PAIRED>)
-            static_assert(kMaxFramesPerLaunch == 32, "one frame per lane of a half-wave");
-            int cls = classify_patch<true>(p, class_pose(s_frames[lane & 31]), xa, xa + p.brick_q * 4 - 1, ya,
-                                           min(ya + p.brick_r - 1, p.dim_y - 1), p.z_begin + z0, p.z_begin + z1);
-            if (g >= p.brick_groups || lane >= mp.n_frames) cls = 0;
-            const unsigned long long fb = __ballot(cls == 1), sb = __ballot(cls == 2);
-            free_frames = (unsigned int)fb;
-            skip_frames = (unsigned int)sb;
-            if (p.claim_counter != nullptr && lane == 0) {
-                // one global atomic per workgroup: the wavefronts add up in LDS, the last one to arrive passes the sum on
-                if (fb != 0ull) atomicAdd(&s_claims[0], (unsigned)__popcll(fb));
-                if (sb != 0ull) atomicAdd(&s_claims[1], (unsigned)__popcll(sb));
-                __threadfence_block();
-                if (atomicAdd(&s_done, 1u) == 3u) {
-                    __threadfence_block();
-                    const unsigned long long nf = s_claims[0], ns = s_claims[1];
-                    if ((nf | ns) != 0ull) atomicAdd(p.claim_counter, (nf << 32) | ns);
-                }
-            }
-        } else {
-            free_frames = s_bits[0];
-            skip_frames = s_bits[1];
-        }
-        free_frames = __builtin_amdgcn_readfirstlane(free_frames);
-        skip_frames = __builtin_amdgcn_readfirstlane(skip_frames);
-    }
-    multi_body<R, NT, FLAT, LABELS, MASKS, SHORT, BRICK>(mp.common, (const FramePose *)frames, mp.n_frames,
-                                                         BRICK ? wg_x * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.y) : wg_x,
-                                                         wg_y, wg_z, mp.labels, free_frames, skip_frames);
-}
-
-// Ahead of a BRICK launch: which frames may do something to each super-brick -- the box of a workgroup's four bricks over
-// kSuperZ consecutive slice groups -- one WAVEFRONT per super-brick, one frame per lane (paired half-waves, as in the
-// launch's own prologue; the same classify_patch, so the same exactness argument, on a larger box).  Most of a realistic
-// launch's workgroups are skipped by every frame (the volume behind the surfaces and outside the views: 45 % of S-surf's
-// workgroups, more on a trajectory); with their word 0 they cost a dispatch instead of staging + barrier + four
-// classifications.  grid = ceil(super-bricks / 4) x 256 threads.
-__global__ __launch_bounds__(256) void classify_superbricks(MultiParamsInline mp, unsigned int *out, int n_wgx)
-{
-    typedef const char __attribute__((address_space(4))) *kernarg_ptr;
-    kernarg_ptr base = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
-    const FramePose *frames = (const FramePose *)(base + offsetof(MultiParamsInline, frames));
-    const IntegrateParams &p = mp.common;
-    const int id = (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.y), lane = threadIdx.x;
-    if (id >= n_wgx * mp.nz_super) return;
-    const int wx = id / mp.nz_super, zs = id - wx * mp.nz_super;
-    const int total = p.brick_groups * p.bricks_per_group;
-    const int b0 = wx * 4, b3 = min(b0 + 3, total - 1);
-    if (b0 >= total) {
-        if (lane == 0) out[id] = 0u;
-        return;
-    }
-    const int g0 = b0 / p.bricks_per_group, i0 = b0 - g0 * p.bricks_per_group;
-    const int g3 = b3 / p.bricks_per_group, i3 = b3 - g3 * p.bricks_per_group;
-    // the four bricks lie side by side in one row group, or wrap into the next one (then: the full width of both)
-    const int xa = g0 == g3 ? i0 * p.brick_q * 4 : 0, xb = g0 == g3 ? (i3 + 1) * p.brick_q * 4 - 1 : p.dim_x - 1;
-    const int ya = g0 * p.brick_r, yb = min((g3 + 1) * p.brick_r - 1, p.dim_y - 1);
-    const int nz_groups = (p.nz + p.brick_s - 1) / p.brick_s;
-    const int zg0 = zs * kSuperZ, zg1 = min(zg0 + kSuperZ - 1, nz_groups - 1);
-    const int z0 = zg0 * p.brick_s, z1 = min((zg1 + 1) * p.brick_s - 1, p.nz - 1);
-    const int cls = classify_patch<true>(p, class_pose(frames[lane & 31]), xa, xb, ya, yb, p.z_begin + z0, p.z_begin + z1);
-    const unsigned long long work = __ballot(cls != 2 && lane < mp.n_frames);
-    if (lane == 0) out[id] = (unsigned int)work;
+    multi_body<R, NT, FLAT, LABELS, MASKS>(mp.common, (const FramePose *)frames, mp.n_frames, wg_x, wg_y, wg_z, mp.labels);
 }
 
 // ---- live bricks only: a compacted work list -------------------------------------------------------------------------
@@ -1271,35 +1084,12 @@ __global__ __launch_bounds__(256, LABELS ? 6 : TSDF_BRICK_WAVES) void integrate_
     multi_body<1, NT, false, LABELS, MASKS, true, true>(mp.common, frames, mp.n_frames, brick, 0, zg, mp.labels, free_frames, skip_frames);
 }
 
-// Experiment (variant 5): XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs, so
-// ids b and b + 8 share an L2; this remap hands each XCD one contiguous eighth of the slab instead of
-// every eighth workgroup.  Measured: no gain -- the only shared data is the 1.2 MB
-// depth frame, which every XCD's 4 MiB L2 holds whole either way; volume bytes are touched once.
-template <bool NT>
-__global__ __launch_bounds__(256) void integrate_multi_xcd(MultiParams mp)
-{
-    const unsigned nx = gridDim.x, ny = gridDim.y, n = nx * ny * gridDim.z;
-    unsigned id = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
-    if (n % 8u == 0u) id = (id % 8u) * (n / 8u) + id / 8u;
-    const unsigned bx = id % nx, t = id / nx;
-    multi_body<1, NT, false>(mp.common, mp.frames, mp.n_frames, (int)bx, (int)(t % ny), (int)(t / ny));
-}
-
 // One frame, pose by value (no frame block in memory to stage): what a single tsdf_integrate* call
 // on a volume served by the flat mapping launches.
-// CLS: with a workgroup class table (IntegrateParams::wg_class, classify_workgroups): skipped workgroups leave at
-// once, free-space ones only add to their weights.
-template <bool NT, bool FLAT, bool CLS = false>
+template <bool NT, bool FLAT>
 __global__ __launch_bounds__(256) void integrate_multi_single(IntegrateParams p, FramePose pose)
 {
-    if constexpr (CLS) {
-        const unsigned id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        const unsigned c = p.wg_class[id];
-        if (c == 2u) return;
-        multi_body<1, NT, FLAT, false, true, true>(p, &pose, 1, blockIdx.x, blockIdx.y, blockIdx.z, LabelState(), c == 1u ? 1u : 0u, 0u);
-    } else {
-        multi_body<1, NT, FLAT>(p, &pose, 1, blockIdx.x, blockIdx.y, blockIdx.z);
-    }
+    multi_body<1, NT, FLAT>(p, &pose, 1, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Many volumes, one frame, one launch (the reference's real usage: one small TSDF per object
@@ -1307,26 +1097,16 @@ __global__ __launch_bounds__(256) void integrate_multi_single(IntegrateParams p,
 // params[o] / poses[o]: the parameter block and this frame's relative pose + mask of object o (each has
 // its own base frame); slice_map[z] = {object, slice within it} for every slice of every object;
 // grid = (max blocks per slice, 1, total slices).  Flat mapping: object grids are small and rarely
-// 256 wide.  The blocks are read through a wave-uniform index (scalar loads).
-// wg_class (may be null): class of every workgroup of this launch for this frame (classify_workgroups_batched):
-// per-object volumes are fed depth x their instance mask, so most of their workgroups see nothing and leave at once.
-template <bool NT, bool CLS>
+// 256 wide.  The blocks are read through a wave-uniform index (scalar loads).  (Launches large enough to repay a class
+// table run over bricks: integrate_multi_batched_bricks.)
+template <bool NT>
 __global__ __launch_bounds__(256) void integrate_multi_batched(const IntegrateParams *__restrict__ params,
                                                                const FramePose *__restrict__ poses,
-                                                               const int2 *__restrict__ slice_map,
-                                                               const uint8_t *__restrict__ wg_class)
+                                                               const int2 *__restrict__ slice_map)
 {
-    unsigned c = 0u;
-    if constexpr (CLS) {
-        c = wg_class[blockIdx.x + gridDim.x * blockIdx.z];
-        if (c == 2u) return;
-    }
     const int2 m = slice_map[blockIdx.z];
     const IntegrateParams p = params[m.x];
-    if constexpr (CLS)
-        multi_body<1, NT, true, false, true, true>(p, poses + m.x, 1, blockIdx.x, 0, m.y, LabelState(), c == 1u ? 1u : 0u, 0u);
-    else
-        multi_body<1, NT, true>(p, poses + m.x, 1, blockIdx.x, 0, m.y);
+    multi_body<1, NT, true>(p, poses + m.x, 1, blockIdx.x, 0, m.y);
 }
 
 // One masked frame into one volume over bricks with a class per wavefront (classify_bricks); grid.z = slice groups.

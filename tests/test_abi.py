@@ -99,3 +99,21 @@ def test_no_gpu_means_loud_failure_not_fallback():
         pytest.skip("a GPU is present")
     with pytest.raises(capi.TsdfError, match="no HIP device|CPU path"):
         capi.Volume(capi.default_config())
+
+
+def test_measurement_build_compiles_and_knows_the_experiment_variants():
+    """`make experiments` (-DTSDF_EXPERIMENTS): the product plus the kernel variants of csrc/tsdf_experiments.hip.h.  It is not
+    what ships and nothing loads it by default; this keeps it compiling, and checks that the shipped library refuses the
+    experiment numbers while the measurement build reports itself (host-only calls: no GPU needed)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "semantic_slam_amd", "csrc"), "experiments"])
+    exp = os.path.join(root, "semantic_slam_amd", "libtsdf_hip_exp.so")
+    assert os.path.isfile(exp)
+    code = ("from semantic_slam_amd import capi; print(capi.experiments_build(), capi.variants(0, 1, 2, 3, 7, 8, 11, 13, 23, 119))")
+    out = subprocess.check_output([sys.executable, "-c", code], cwd=root, env=dict(os.environ, TSDF_HIP_LIB=exp), text=True)
+    assert out.strip() == "True [0, 1, 2, 3, 7, 8, 11, 13, 23, 119]"
+    env = {k: v for k, v in os.environ.items() if k != "TSDF_HIP_LIB"}
+    out = subprocess.check_output([sys.executable, "-c", code], cwd=root, env=env, text=True)
+    assert out.strip() == "False [0, 1, 3, 7, 8]"

@@ -26,7 +26,7 @@ def run_case(cuda, oracle, dims, vs, origin, K, frames, expect_claims=True, trun
             oracle.integrate(cfg.cam_K, c2w, depth, dims, origin, vs, cfg.trunc_margin, ref_t, ref_w, threads=8)
     keep = [cuda.from_numpy(np.ascontiguousarray(d, np.float32)).cuda() for _, d in frames]
     poses = np.stack([p for p, _ in frames])
-    for variant in (8, 12, 13, 11, 0, 7):     # bricks per wavefront with / without the super-brick pre-pass, rows per workgroup (all forced), per launch, never
+    for variant in capi.variants(8, 0, 7, 12, 13, 11):     # bricks per wavefront with / without the super-brick pre-pass, rows per workgroup (all forced), per launch, never
         with capi.Volume(cfg) as vol:
             vol.set_kernel_variant(variant)
             if variant in (8, 11, 12, 13):

@@ -37,7 +37,7 @@ def random_case(seed):
 
 # 0: classification decided per launch, 7: never, 8: always (bricks per wavefront), 11: always (rows per workgroup)
 # -- all inside the driver's single pytest run (no env knob)
-@pytest.mark.parametrize("variant", [0, 7, 8, 11])
+@pytest.mark.parametrize("variant", capi.variants(0, 7, 8, 11, 13))
 @pytest.mark.parametrize("seed", range(40))
 def test_random_configuration(cuda, oracle, seed, variant):
     rng, dims, h, w, K, vs, origin, trunc, max_depth = random_case(seed)

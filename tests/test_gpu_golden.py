@@ -9,7 +9,7 @@ from semantic_slam_amd import capi
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("variant", [0, 3, 1, 2])   # 0: collected frames, 3: one default kernel per frame, 1 / 2: first versions
+@pytest.mark.parametrize("variant", capi.variants(0, 3, 1, 2))   # 0: collected frames, 3: one default kernel per frame, 1 / 2: first versions
 @pytest.mark.parametrize("name", NAMES)
 def test_hip_reproduces_golden(cuda, name, variant):
     g = Golden(name)

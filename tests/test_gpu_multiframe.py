@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("dims", [(256, 42, 30), (200, 42, 30), (36, 20, 12)])   # row mapping, flat, flat + partial chunk
-@pytest.mark.parametrize("variant", [0, 4, 3, 5, 8, 9, 10, 11, 12, 13])   # 9: memory-order dispatch; 10: slices fastest without the rotation; 12: bricks without the super-brick pre-pass; 11: rows classified per workgroup (default: bricks per wavefront)
+@pytest.mark.parametrize("variant", capi.variants(0, 3, 7, 8, 4, 5, 6, 9, 10, 11, 12, 13))   # 9: memory-order dispatch; 10: slices fastest without the rotation; 12: bricks without the super-brick pre-pass; 11: rows classified per workgroup (default: bricks per wavefront)
 @pytest.mark.parametrize("n_frames", [1, 3, 4, 9, 32, 33, 70])   # kMaxFramesPerLaunch = 32: one full pass, +1, 2 full + 6
 def test_fused_frames_equal_sequential_and_oracle(cuda, oracle, n_frames, variant, dims):
     if n_frames > 9 and (variant != 0 or dims[0] == 36):
@@ -160,7 +160,7 @@ def test_classification_is_dropped_when_it_claims_nothing_and_probed_again(cuda,
     assert np.array_equal(w, ref_w) and np.array_equal(t.view(np.uint32), ref_t.view(np.uint32))
 
 
-@pytest.mark.parametrize("variant", [8, 11])
+@pytest.mark.parametrize("variant", capi.variants(8, 11, 13))
 def test_runs_of_free_space_frames_with_awkward_weights(cuda, oracle, variant):
     """A run of claimed free-space frames moves the weights by its length at once -- only when that is the same bits
     as that many "+ 1": weights that are not integers (an upload), weights at and around 2^24 (where w + 1 == w) and

@@ -80,9 +80,11 @@ def test_integrate_matches_oracle(cuda, oracle, dims, vs, z0, rand_base, frames,
 SUM_VARIANTS = [b + c for b in (32, 48, 64, 80, 96) for c in (2, 3, 6, 7, 10, 11)] + [115, 119]   # 11x: depth tile in LDS
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2] + list(range(16, 28)) + SUM_VARIANTS)
+@pytest.mark.parametrize("variant", capi.variants(*([0, 1, 3, 2] + list(range(16, 28)) + SUM_VARIANTS)))
 def test_every_kernel_variant_is_bit_exact(cuda, oracle, variant):
-    """All kernel variants (rows/tile, R = 1/2/4, elision on/off, nt on/off) give identical bits.
+    """Every one-frame kernel the loaded library has gives identical bits: the shipped ones (default, one launch per frame,
+    scalar) and -- when the measurement build is loaded (TSDF_HIP_LIB=.../libtsdf_hip_exp.so) -- every stage of the ladder
+    (rows/tile, R = 1/2/4, elision on/off, nt on/off, summary, early loads, fast projection, LDS depth tiles).
     The scene has free space (elided divisions), a truncation band and repeated frames, so both
     sides of every wave-uniform shortcut are taken; dim_y = 50 leaves ragged row groups.  dim_x = 256
     keeps the row-mapped kernels in play (other widths are served by the flat mapping, tested above)."""
@@ -127,7 +129,7 @@ def test_free_space_summary_stays_consistent(cuda, oracle):
         step(far, p0, 0)                      # all segments stay "ones"
         step(scene.depth(p0), p0, 0)          # surface: some segments leave the ones state
         step(far, p1, 0)                      # free space again over changed segments: must use real TSDF
-        step(scene.depth(p1), p1, 2)          # a kernel without summary support
+        step(scene.depth(p1), p1, 1)          # a kernel without summary support (the scalar one)
         step(far, p0, 0)                      # back on the summary kernel
         t, w = vol.download()
         assert_parity(t, w, ref_t, ref_w)
@@ -141,7 +143,7 @@ def test_free_space_summary_stays_consistent(cuda, oracle):
         vol.reset()
         ref_t[:], ref_w[:] = 1.0, 0.0
         step(far, p0, 0)
-        step(scene.depth(p0), p0, 39)
+        step(scene.depth(p0), p0, 39 if capi.experiments_build() else 3)   # 39: the summary kernel without the fast projection (measurement build)
         t, w = vol.download()
         assert_parity(t, w, ref_t, ref_w)
         assert np.count_nonzero(ref_t != 1.0) > 1000
@@ -500,7 +502,7 @@ def test_non_finite_depth_samples(cuda, oracle, dims):
     assert np.isfinite(ref_t).all() and ref_w.max() >= 3
     keep = [dev(cuda, d) for _, d in frames]
     poses = np.stack([c for c, _ in frames])
-    for variant, fused in ((0, False), (0, True), (2, False), (17, False)):
+    for variant, fused in [(0, False), (0, True), (3, False), (1, False)] + ([(2, False), (17, False)] if capi.experiments_build() else []):
         if dims[0] % 4 and (fused or variant):
             continue
         with capi.Volume(cfg) as vol:

@@ -91,7 +91,7 @@ def test_reference_kernel_oracle_and_product_agree_on_random_inputs(cuda, oracle
         oracle.integrate(K, c2b, depth, dims, origin, vs, trunc, ot, ow, threads=4)
     assert rw.sum() > 0
     assert np.array_equal(ow, rw) and np.array_equal(ot.view(np.uint32), rt.view(np.uint32))
-    for variant, fused in ((3, False), (0, False), (0, True), (8, True), (2, False)):
+    for variant, fused in ((3, False), (0, False), (0, True), (8, True), (7, True), (1, False)) + (((2, False), (23, False)) if capi.experiments_build() else ()):
         pt, pw = _product_run(cuda, K, frames, dims, origin, vs, trunc, h, w, variant, fused)
         assert np.array_equal(pw, rw), (variant, fused)
         assert np.array_equal(pt.view(np.uint32), rt.view(np.uint32)), (variant, fused)

@@ -68,7 +68,7 @@ def _reference(torch, name):
     return wv.replay(torch, name + "512", cfg.cam_K, dims, cfg.origin, cfg.voxel_size, cfg.trunc_margin, poses, dev)
 
 
-PATHS = ["frame", "fused", "fused_bricks", "fused_per_voxel", "fused_rows", "host_deferred"]
+PATHS = ["frame", "fused", "fused_bricks", "fused_per_voxel", "host_deferred"] + (["fused_rows", "fused_brick_workgroups"] if capi.experiments_build() else [])
 
 
 def _run_path(vol, path, poses, dev, host):
@@ -80,7 +80,7 @@ def _run_path(vol, path, poses, dev, host):
         for p, d in zip(poses, host):
             vol.integrate(d, p)
     else:                                     # a known sequence: fused, classification per launch / always / never / round-1 rows
-        vol.set_kernel_variant({"fused": 0, "fused_bricks": 8, "fused_per_voxel": 7, "fused_rows": 11}[path])
+        vol.set_kernel_variant({"fused": 0, "fused_bricks": 8, "fused_per_voxel": 7, "fused_rows": 11, "fused_brick_workgroups": 13}[path])
         vol.integrate_frames_device([d.data_ptr() for d in dev], poses)
 
 
