@@ -350,7 +350,6 @@ int tsdf_set_kernel_variant(tsdf_volume *vol, int32_t variant);
  * classifies as a whole, in the classified launches (bricks): `quads` x 4 voxels of `rows` rows of `slices`
  * slices.  Needs quads * rows * slices <= 64 and quads dividing dim_x / 4; (0, 0, 0) returns to the library's choice
  * for the grid.  tsdf_brick_shape reads the shape in use ({0, 0, 0}: the grid has no brick view, dim_x % 4 != 0).
- * The environment variable TSDF_BRICK3D="q,r,s" overrides the library's choice at tsdf_create (A/B runs).
  */
 int tsdf_set_brick_shape(tsdf_volume *vol, int32_t quads, int32_t rows, int32_t slices);
 int tsdf_brick_shape(const tsdf_volume *vol, int32_t shape_out[3]);
@@ -403,6 +402,14 @@ int tsdf_download_labels(tsdf_volume *vol, uint16_t *label_host, float *fp_host,
  *                                 pinned staging, integrates, then fuses colour; the call does not wait
  *   tsdf_download_colour          copy the packed colours out (tsdf_slab_voxels() uint32)
  * With colour enabled tsdf_save_mesh_ply writes per-vertex red/green/blue (the nearest voxel's colour).
+ * The colour pass has no weight of its own: it takes w_new from the weight array the geometry pass has just written and
+ * w_old = w_new - 1 (the package's obs_weight = 1).  So (i) a frame integrated WITHOUT a colour image (tsdf_integrate*, or
+ * TSDFfusion::Integrate with an empty colour Mat) still raises the weight, and later colour frames are blended as if that
+ * frame had confirmed the colour the voxel already had -- the behaviour of the package when every frame brings colour, a
+ * documented deviation otherwise; (ii) past 2^24 updates of one voxel w_new - 1 is no longer exact in fp32 (the weights
+ * themselves stop counting there, as the reference's do).  The pass re-derives the frame's updated voxels with the same
+ * projection code as Integrate; tests/test_gpu_colour.py checks the two sets voxel for voxel on poses that send wavefronts of
+ * both kernels down the generic projection.
  */
 int tsdf_colour_enable(tsdf_volume *vol);
 int tsdf_integrate_colour_device(tsdf_volume *vol, const float *depth_dev, const uint8_t *rgb_dev,

@@ -3,8 +3,10 @@
  *
  * TEST INFRASTRUCTURE, never linked into the product.  GpuIntegrate (the reference's only __global__,
  * src/tsdf.cu:15-60) is valid HIP as it stands: hipcc itself supplies __global__, blockIdx, threadIdx,
- * roundf and fmin.  `make -C oracle ref_hip` streams that function from where it lies into hipcc's stdin
- * with NO -include and nothing substituted (oracle/Makefile), and links the object with this file, which
+ * roundf and fmin.  `make -C oracle ref_hip` slices that function, from where it lies, into a temporary file outside the
+ * repository (hipcc reads a translation unit twice, so it cannot come from a pipe), compiles it with
+ * `-include hip/hip_runtime.h` -- the toolchain's own header, as nvcc force-includes cuda_runtime.h into a .cu file; nothing
+ * written by this project, nothing substituted (oracle/Makefile) -- deletes the file, and links the object with this file, which
  * only declares the kernel and launches it with the reference's own shape <<<dim_z, dim_y>>>
  * (src/tsdf.cu:165: one block per z, one thread per y, each looping over x).  The result,
  * oracle/_ref/libtsdf_ref_hip.so, is "the reference compiled here": tests/test_gpu_ref_kernel.py runs it on

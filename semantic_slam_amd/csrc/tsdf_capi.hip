@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "pose_math.h"
+#include "frame_store.h"
 #include "tsdf_kernels.hip.h"
 #include "tsdf_multiframe.hip.h"
 #include "tsdf_labels.hip.h"
@@ -76,32 +77,27 @@ struct tsdf_volume {
     float *d_weight;
     hipStream_t own_stream;
     hipStream_t stream;      // the stream work is queued on (own_stream unless overridden)
-    // host->device staging of depth frames
-    float *h_stage[kStageSlots];
-    float *d_stage[kStageSlots];
-    uint16_t *d_raw[kStageSlots];   // raw 16-bit frames (allocated on first tsdf_integrate_u16)
-    hipEvent_t stage_done[kStageSlots];
-    bool stage_used[kStageSlots];
-    int stage_next;
+    // Staging and deferral memory is not the handle's: pinned frames, frame / mask slots in HBM and depth tile tables come from
+    // the store all handles of this device and image size share (frame_store.h) and go back to it by stream order.
+    tsdf_store::FrameStore *store;
     // the H2D copy of a frame runs on its own stream and overlaps the previous frame's kernel; the kernel waits for it
     hipStream_t copy_stream;
-    hipEvent_t copy_done[kStageSlots];
-    bool copy_used[kStageSlots];
+    hipEvent_t flush_done;            // recorded on `stream` after every launch that read store slots: what they are released after
+    int table_slot;                   // the store's table slot of the launch being queued, or -1
     // Deferred integration of host frames (tsdf_integrate): the reference reads results back only in its destructor
     // (ref: src/tsdf.cu:101-104) and this library only at download / extraction / save, so the frames of successive
     // calls are collected -- copied into a pool in HBM, poses composed at call time -- and applied defer_n at a time as
     // ONE fused, classified sequence launch; every entry point that observes or changes the volume flushes first.
     int defer_n;                      // frames per deferred launch (<= 1: every call launches; default kMaxFramesPerLaunch)
-    float *d_pool[2];                 // two pools of defer_n frames: one being filled, one being read by a launch
-    hipEvent_t pool_done[2];
-    bool pool_used[2];
     hipEvent_t pend_copied;
-    int pool_cur, pend_count;
+    int pend_count;
+    int pend_slot[tsdfk::kMaxFramesPerLaunch], pend_mask_slot[tsdfk::kMaxFramesPerLaunch];   // store slots of the collected frames (-1: none)
+    const float *pend_depth[tsdfk::kMaxFramesPerLaunch];
     struct tsdf_batch *owner;   // the batch this handle is a member of (its collected frames come first), or null
+    struct tsdf_group *group_owner;   // the group this handle is a slab of (likewise), or null
     bool in_flush;
     float pend_c2b[16 * tsdfk::kMaxFramesPerLaunch];
-    uint8_t *d_mask_pool[2];          // instance masks of collected masked frames (allocated on first use)
-    const uint8_t *pend_mask[tsdfk::kMaxFramesPerLaunch];
+    const uint8_t *pend_mask[tsdfk::kMaxFramesPerLaunch];   // instance masks of collected masked frames (in the store's mask slots)
     int variant;
     // per-launch frame blocks of integrate_multi: pinned host ring -> device ring (allocated on first use)
     tsdfk::FramePose *h_frames[kStageSlots];
@@ -117,6 +113,9 @@ struct tsdf_volume {
     uint32_t *d_colour;
     uint8_t *d_rgb[kStageSlots];
     uint8_t *h_rgb[kStageSlots];
+    hipEvent_t rgb_done[kStageSlots];
+    bool rgb_used[kStageSlots];
+    int rgb_next;
     // free-space summary (one word per 256-voxel row segment), see tsdf_kernels.hip.h
     uint32_t *d_flags;
     size_t n_flags;
@@ -130,8 +129,7 @@ struct tsdf_volume {
     uint4 *d_work;               // work list of the current fused brick launch: {brick, slice group, free frames, skipped frames}
     size_t work_entries;         // per live brick (classify_brick_list); capacity = every brick of the slab
     int64_t work_nsuper, work_bucket_supers;   // super-bricks of the shape the list was sized for; most of them in one sub-list
-    // depth tile summaries of the frames of one fused launch (allocated on first use), optional counters
-    float2 *d_tiles;
+    // optional diagnostic counters (tsdf_shortcut_stats)
     unsigned int *d_shortcut_stats;
     // adaptive use of the classification: claims of the last classifying launch, read back without blocking
     unsigned long long *d_claims, *h_claims;
@@ -197,7 +195,9 @@ struct tsdf_batch {
 namespace {
 
 int flush_pending(tsdf_volume *v);
+int fail(int code, const char *fmt, ...);
 int batch_flush(tsdf_batch *b);
+int group_flush(tsdf_group *g);   // tsdf_group.hip.h
 int batch_collect(tsdf_batch *b, const float *depth_dev, const uint8_t *const *masks_dev, const float cam2world[16]);
 
 // Every entry point starts here: make the handle's device current and, unless the caller is the collecting call itself,
@@ -209,8 +209,57 @@ int bind_device(tsdf_volume *v, bool flush = true)
         int rc = batch_flush(v->owner);
         if (rc) return rc;
     }
+    if (v->group_owner && !v->in_flush) {   // likewise the frames its group has collected (a slab handle borrowed with tsdf_group_volume)
+        int rc = group_flush(v->group_owner);
+        if (rc) return rc;
+    }
     if (flush && v->pend_count > 0 && !v->in_flush) return flush_pending(v);
     return TSDF_OK;
+}
+
+// ---- the shared store (frame_store.h) -----------------------------------------------------------------------------
+// A frame (c = frames) or mask (c = masks) slot whose first access is queued on `first_user`.  When the store is at its soft
+// cap and every slot is held by collecting handles, this handle applies what IT has collected (never another handle's: that
+// one may be in use on another thread) and asks again.
+int store_slot(tsdf_volume *v, tsdf_store::SlotClass *c, hipStream_t first_user, int *index, void **dev)
+{
+    hipError_t e = tsdf_store::slot_acquire(v->store, c, v, first_user, false, index, dev);
+    if (e == hipSuccess && *index < 0) {
+        if (v->pend_count > 0 && !v->in_flush) {
+            int rc = flush_pending(v);
+            if (rc) return rc;
+        }
+        e = tsdf_store::slot_acquire(v->store, c, v, first_user, true, index, dev);
+    }
+    if (e != hipSuccess) return fail(TSDF_ERR_HIP, "frame store: %s", hipGetErrorString(e));
+    return TSDF_OK;
+}
+
+// Everything queued on the handle's stream so far has read its store slots: they go back after flush_done.
+int store_release(tsdf_volume *v, tsdf_store::SlotClass *c, const int *idx, int n)
+{
+    HIP_TRY(hipEventRecord(v->flush_done, v->stream));
+    tsdf_store::slots_release_after(v->store, c, idx, n, &v->flush_done, v);
+    return TSDF_OK;
+}
+
+// The depth tile tables of the launch being queued (kMaxFramesPerLaunch tables): a table slot of the store, first written on the
+// handle's stream; tables_end() after the launch that reads them has been queued.
+int tables_begin(tsdf_volume *v, float2 **tiles)
+{
+    void *dev = nullptr;
+    hipError_t e = tsdf_store::slot_acquire(v->store, &v->store->tables, v, v->stream, true, &v->table_slot, &dev);
+    if (e != hipSuccess) return fail(TSDF_ERR_HIP, "frame store (tile tables): %s", hipGetErrorString(e));
+    *tiles = static_cast<float2 *>(dev);
+    return TSDF_OK;
+}
+
+int tables_end(tsdf_volume *v)
+{
+    if (v->table_slot < 0) return TSDF_OK;
+    const int slot = v->table_slot;
+    v->table_slot = -1;
+    return store_release(v, &v->store->tables, &slot, 1);
 }
 
 // The wavefront brick of classified launches: q quads (4q voxels) of r rows of s slices, q * r * s <= 64 lanes, q a
@@ -227,13 +276,15 @@ void choose_brick_for(const tsdf_config &c, int &bq, int &br, int &bs)
     bq = 0; br = 0; bs = 1;
     if (c.dim_x % 4 != 0) return;
     const int quads = c.dim_x / 4;
-    if (const char *e = std::getenv("TSDF_BRICK3D")) {      // A/B knob: "q,r,s"
+#ifdef TSDF_EXPERIMENTS
+    if (const char *e = std::getenv("TSDF_BRICK3D")) {      // A/B knob of the measurement build: "q,r,s" (the product: tsdf_set_brick_shape)
         int q = 0, r = 0, sl = 0;
         if (std::sscanf(e, "%d,%d,%d", &q, &r, &sl) == 3 && brick_shape_ok(c, q, r, sl)) {
             bq = q; br = r; bs = sl;
             return;
         }
     }
+#endif
     // The library's choice: the shape that lets the fewest bricks touch a surface band.  A brick of X x Y x Z voxels is
     // claimed unless the band (about 10 voxels thick) crosses its box grown by the slack of the depth tiles it is tested
     // against (about 8 voxels either way in x and y at the usual 1 - 2 pixels per voxel), so the share of per-voxel
@@ -426,8 +477,9 @@ int build_tile_tables(hipStream_t stream, const tsdf_config &c, const tsdfk::Int
 int launch_masked_bricks(tsdf_volume *v, tsdfk::IntegrateParams &p)
 {
     const int blocks = (p.brick_groups * p.bricks_per_group + 3) / 4, nz = (p.nz + p.brick_s - 1) / p.brick_s;   // slice groups
-    const size_t per = tile_table_elems_host(p.tiles_w, p.tiles_h);
-    if (!v->d_tiles) HIP_TRY(hipMalloc((void **)&v->d_tiles, tsdfk::kMaxFramesPerLaunch * per * sizeof(float2)));
+    float2 *tiles = nullptr;
+    int rc0 = tables_begin(v, &tiles);
+    if (rc0) return rc0;
     const size_t n_bricks = (size_t)blocks * nz * 4;
     if (v->wg_class_bytes < n_bricks) {
         if (v->d_wg_class) HIP_TRY(hipFree(v->d_wg_class));
@@ -438,17 +490,17 @@ int launch_masked_bricks(tsdf_volume *v, tsdfk::IntegrateParams &p)
     }
     const float *d = p.depth;
     const uint8_t *m = p.mask;
-    int rc = build_tile_tables(v->stream, v->cfg, p, &d, &m, 1, v->d_tiles);
+    int rc = build_tile_tables(v->stream, v->cfg, p, &d, &m, 1, tiles);
     if (rc) return rc;
     tsdfk::FramePose pose;
     pose_from_params(pose, p);
-    pose.tiles = v->d_tiles;
+    pose.tiles = tiles;
     hipLaunchKernelGGL(tsdfk::classify_bricks, dim3((unsigned)((n_bricks + 255) / 256)), dim3(256), 0, v->stream, p, pose,
                        v->d_wg_class, blocks, nz);
     p.wg_class = v->d_wg_class;
     hipLaunchKernelGGL((tsdfk::integrate_single_bricks<true>), dim3(blocks, 1, nz), dim3(64, 4, 1), 0, v->stream, p, pose);
     HIP_TRY(hipGetLastError());
-    return TSDF_OK;
+    return tables_end(v);
 }
 
 // Kernel variants (tsdf_set_kernel_variant) of the library as shipped:
@@ -660,10 +712,12 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
     if (classify) {
         // depth tile tables of the n frames (two small launches), then the kernels that consult them
         const size_t per_frame = tile_table_elems_host(mi.common.tiles_w, mi.common.tiles_h);
-        if (!v->d_tiles) HIP_TRY(hipMalloc((void **)&v->d_tiles, tsdfk::kMaxFramesPerLaunch * per_frame * sizeof(float2)));
-        int rc = build_tile_tables(v->stream, c, mi.common, depth_dev, masks_dev, n, v->d_tiles, v->d_claims);
+        float2 *tiles = nullptr;
+        int rc = tables_begin(v, &tiles);
         if (rc) return rc;
-        for (int f = 0; f < n; ++f) mi.frames[f].tiles = v->d_tiles + (size_t)f * per_frame;
+        rc = build_tile_tables(v->stream, c, mi.common, depth_dev, masks_dev, n, tiles, v->d_claims);
+        if (rc) return rc;
+        for (int f = 0; f < n; ++f) mi.frames[f].tiles = tiles + (size_t)f * per_frame;
         for (int f = n; f < tsdfk::kMaxFramesPerLaunch; ++f) mi.frames[f] = mi.frames[0];
     }
     const int nz_groups = (nz + mi.common.brick_s - 1) / mi.common.brick_s;   // a brick spans brick_s slices
@@ -750,7 +804,7 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
         v->claims_pending = true;
     }
     HIP_TRY(hipGetLastError());
-    return TSDF_OK;
+    return tables_end(v);
 }
 
 // Frames applied per pass over the slab.  Per frame the time is a + b / n: the weights are read and written,
@@ -784,95 +838,117 @@ int integrate_frames(tsdf_volume *v, const float *const *depth_dev, const uint8_
     return rc;
 }
 
-// Apply the collected host frames (poses already composed) as one sequence.
+// Apply the collected frames (poses already composed) as one sequence; their store slots go back after the launch.
 int flush_pending(tsdf_volume *v)
 {
     if (v->pend_count == 0 || v->in_flush) return TSDF_OK;
     v->in_flush = true;
-    const int n = v->pend_count, p = v->pool_cur;
+    const int n = v->pend_count;
     v->pend_count = 0;
-    v->pool_cur = p ^ 1;
-    const size_t px = (size_t)v->cfg.im_height * v->cfg.im_width;
     int rc = TSDF_OK;
     hipError_t e = hipSetDevice(v->cfg.device);
-    // the batch's copies ran in order on the copy stream: one event after the last of them covers all
+    // the frames' copies ran in order on the copy stream: one event after the last of them covers all
     if (e == hipSuccess) e = hipEventRecord(v->pend_copied, v->copy_stream);
     if (e == hipSuccess) e = hipStreamWaitEvent(v->stream, v->pend_copied, 0);
     if (e == hipSuccess) {
-        const float *ptrs[tsdfk::kMaxFramesPerLaunch];
         bool any_mask = false;
-        for (int f = 0; f < n; ++f) {
-            ptrs[f] = v->d_pool[p] + (size_t)f * px;
-            any_mask = any_mask || v->pend_mask[f] != nullptr;
-        }
+        for (int f = 0; f < n; ++f) any_mask = any_mask || v->pend_mask[f] != nullptr;
         if (can_fuse(v) && n > 1) {
-            rc = launch_multi(v, ptrs, any_mask ? v->pend_mask : nullptr, v->pend_c2b, n);
+            rc = launch_multi(v, v->pend_depth, any_mask ? v->pend_mask : nullptr, v->pend_c2b, n);
         } else {   // a single collected frame (or a variant that does not fuse): the one-frame kernels
-            for (int f = 0; f < n && rc == TSDF_OK; ++f) rc = launch_integrate(v, ptrs[f], v->pend_mask[f], v->pend_c2b + 16 * f);
+            for (int f = 0; f < n && rc == TSDF_OK; ++f) rc = launch_integrate(v, v->pend_depth[f], v->pend_mask[f], v->pend_c2b + 16 * f);
         }
-        if (rc == TSDF_OK) {
-            e = hipEventRecord(v->pool_done[p], v->stream);
-            v->pool_used[p] = true;
-        }
+        if (rc == TSDF_OK) rc = store_release(v, &v->store->frames, v->pend_slot, n);
+        if (rc == TSDF_OK && any_mask) rc = store_release(v, &v->store->masks, v->pend_mask_slot, n);
     }
     v->in_flush = false;
     if (e != hipSuccess) return fail(TSDF_ERR_HIP, "deferred integration: %s", hipGetErrorString(e));
     return rc;
 }
 
-// Deferred integration, collecting side: the address in the pool being filled where the next host frame goes (copies into it
-// run on the copy stream) ...
-int pool_slot_begin(tsdf_volume *v, float **dst)
+// Deferred integration, collecting side: a frame slot of the store for the next collected frame; `first_user` is the stream
+// the copy into it will be queued on (the copy stream for host frames, the handle's stream for device-resident ones) ...
+struct Collected {
+    int slot, mask_slot;
+    float *dev;
+    const uint8_t *mask;
+};
+
+int pool_slot_begin(tsdf_volume *v, hipStream_t first_user, Collected *c)
 {
-    const size_t px = (size_t)v->cfg.im_height * v->cfg.im_width, img = px * sizeof(float);
-    const int p = v->pool_cur, slot = v->pend_count;
-    if (!v->d_pool[0]) {
-        for (int i = 0; i < 2; ++i) {
-            HIP_TRY(hipMalloc((void **)&v->d_pool[i], (size_t)tsdfk::kMaxFramesPerLaunch * img));
-            HIP_TRY(hipEventCreateWithFlags(&v->pool_done[i], hipEventDisableTiming));
-        }
-        HIP_TRY(hipEventCreateWithFlags(&v->pend_copied, hipEventDisableTiming));
-    }
-    // the launch that read this pool two batches ago must have finished before frames are copied over it
-    if (slot == 0 && v->pool_used[p]) HIP_TRY(hipStreamWaitEvent(v->copy_stream, v->pool_done[p], 0));
-    *dst = v->d_pool[p] + (size_t)slot * px;
-    return TSDF_OK;
+    c->slot = c->mask_slot = -1;
+    c->mask = nullptr;
+    void *dev = nullptr;
+    int rc = store_slot(v, &v->store->frames, first_user, &c->slot, &dev);   // (may apply the frames collected so far to make room)
+    c->dev = static_cast<float *>(dev);
+    return rc;
 }
 
 // ... and the frame's pose, composed now (or given as the relative pose itself); the batch is launched when it is full.
-int pool_slot_commit(tsdf_volume *v, const float cam2world[16], const float *cam2base = nullptr, const uint8_t *mask = nullptr)
+int pool_slot_commit(tsdf_volume *v, const Collected &c, const float cam2world[16], const float *cam2base = nullptr)
 {
     const int slot = v->pend_count;
+    v->pend_slot[slot] = c.slot;
+    v->pend_mask_slot[slot] = c.mask_slot;
+    v->pend_depth[slot] = c.dev;
+    v->pend_mask[slot] = c.mask;
     if (cam2base) std::memcpy(v->pend_c2b + 16 * slot, cam2base, 16 * sizeof(float));
     else compose_cam2base(v, cam2world, v->pend_c2b + 16 * slot);
-    v->pend_mask[slot] = mask;
     std::memcpy(v->last_cam2base, v->pend_c2b + 16 * slot, sizeof v->last_cam2base);
     v->pend_count = slot + 1;
     if (v->pend_count >= std::min(v->defer_n, (int)tsdfk::kMaxFramesPerLaunch)) return flush_pending(v);
     return TSDF_OK;
 }
 
-// A device-resident frame (and its instance mask) collected like a host frame: copied device to device into the pool on the
-// handle's stream -- the same ordering the frame's kernel would have had -- so the caller's buffer is free for reuse under
+// A device-resident frame (and its instance mask) collected like a host frame: copied device to device into a store slot on
+// the handle's stream -- the same ordering the frame's kernel would have had -- so the caller's buffer is free for reuse under
 // the stream's order, as before.
 int collect_device_frame(tsdf_volume *v, const float *depth_dev, const uint8_t *mask_dev, const float *cam2world,
                          const float *cam2base)
 {
     const size_t px = (size_t)v->cfg.im_height * v->cfg.im_width;
-    float *dst = nullptr;
-    int rc = pool_slot_begin(v, &dst);
+    Collected c;
+    int rc = pool_slot_begin(v, v->stream, &c);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(dst, depth_dev, px * sizeof(float), hipMemcpyDeviceToDevice, v->stream));
-    const uint8_t *mask = nullptr;
+    HIP_TRY(hipMemcpyAsync(c.dev, depth_dev, px * sizeof(float), hipMemcpyDeviceToDevice, v->stream));
     if (mask_dev) {
-        const int p = v->pool_cur;
-        if (!v->d_mask_pool[p]) HIP_TRY(hipMalloc((void **)&v->d_mask_pool[p], (size_t)tsdfk::kMaxFramesPerLaunch * px));
-        uint8_t *m = v->d_mask_pool[p] + (size_t)v->pend_count * px;
+        void *m = nullptr;
+        rc = store_slot(v, &v->store->masks, v->stream, &c.mask_slot, &m);
+        if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(m, mask_dev, px, hipMemcpyDeviceToDevice, v->stream));
-        mask = m;
+        c.mask = static_cast<const uint8_t *>(m);
     }
-    return pool_slot_commit(v, cam2world, cam2base, mask);
+    return pool_slot_commit(v, c, cam2world, cam2base);
 }
+
+// One-kernel-per-call staging of a host frame: pinned ring slot -> frame slot of the store (H2D on the copy stream, which the
+// handle's stream then waits for).  `fill_host(pinned)` writes the pinned frame; *dev = the frame in HBM; *slot goes to
+// stage_end() once the kernels that read it have been queued.
+template <typename F>
+int stage_begin(tsdf_volume *v, size_t bytes, F fill_host, int *slot, void **dev)
+{
+    int r = -1;
+    hipError_t e = tsdf_store::ring_acquire(v->store, &r);
+    if (e != hipSuccess) return fail(TSDF_ERR_HIP, "frame store (pinned ring): %s", hipGetErrorString(e));
+    fill_host(v->store->ring[r].host);                     // the caller may free its buffer after we return
+    int rc = store_slot(v, &v->store->frames, v->copy_stream, slot, dev);
+    if (rc) { (void)tsdf_store::ring_release(v->store, r, v->copy_stream); return rc; }
+    e = hipMemcpyAsync(*dev, v->store->ring[r].host, bytes, hipMemcpyHostToDevice, v->copy_stream);
+    const hipError_t e2 = tsdf_store::ring_release(v->store, r, v->copy_stream);
+    if (e == hipSuccess) e = e2;
+    if (e != hipSuccess) return fail(TSDF_ERR_HIP, "staging copy: %s", hipGetErrorString(e));
+    return TSDF_OK;
+}
+
+// the handle's stream waits for everything queued on the copy stream so far
+int stream_waits_for_copies(tsdf_volume *v)
+{
+    HIP_TRY(hipEventRecord(v->pend_copied, v->copy_stream));
+    HIP_TRY(hipStreamWaitEvent(v->stream, v->pend_copied, 0));
+    return TSDF_OK;
+}
+
+int stage_end(tsdf_volume *v, const int *slots, int n) { return store_release(v, &v->store->frames, slots, n); }
 
 int fill(tsdf_volume *v)
 {
@@ -1073,13 +1149,16 @@ int tsdf_create(const tsdf_config *cfg, tsdf_volume **out)
     v->n_flags = cfg->dim_x % 4 == 0 ? (size_t)v->chunks_per_slice * (size_t)(cfg->z_end - cfg->z_begin) : 0;
     if ((e = hipMalloc((void **)&v->d_flags, (v->n_flags ? v->n_flags : 1) * sizeof(uint32_t))) != hipSuccess)
         return cleanup(fail(TSDF_ERR_HIP, "tsdf_create: hipMalloc of the summary: %s", hipGetErrorString(e)));
-    size_t img = (size_t)cfg->im_height * cfg->im_width * sizeof(float);
-    for (int i = 0; i < kStageSlots; ++i) {
-        if ((e = hipHostMalloc((void **)&v->h_stage[i], img, hipHostMallocDefault)) != hipSuccess ||
-            (e = hipMalloc((void **)&v->d_stage[i], img)) != hipSuccess ||
-            (e = hipEventCreateWithFlags(&v->stage_done[i], hipEventDisableTiming)) != hipSuccess ||
-            (e = hipEventCreateWithFlags(&v->copy_done[i], hipEventDisableTiming)) != hipSuccess)
-            return cleanup(fail(TSDF_ERR_HIP, "tsdf_create: staging alloc: %s", hipGetErrorString(e)));
+    // staging, deferral and tile-table memory: the store shared by every handle of this device and image size (nothing is
+    // allocated until a frame arrives)
+    {
+        const int tw = (cfg->im_width + tsdfk::kTile - 1) / tsdfk::kTile, th = (cfg->im_height + tsdfk::kTile - 1) / tsdfk::kTile;
+        const size_t table_bytes = (int64_t)tw * th <= 16384 ? tsdfk::kMaxFramesPerLaunch * tile_table_elems_host(tw, th) * sizeof(float2) : 0;
+        if ((e = tsdf_store::store_ref(cfg->device, (size_t)cfg->im_height * cfg->im_width, table_bytes, &v->store)) != hipSuccess ||
+            (e = hipEventCreateWithFlags(&v->flush_done, hipEventDisableTiming)) != hipSuccess ||
+            (e = hipEventCreateWithFlags(&v->pend_copied, hipEventDisableTiming)) != hipSuccess)
+            return cleanup(fail(TSDF_ERR_HIP, "tsdf_create: frame store: %s", hipGetErrorString(e)));
+        v->table_slot = -1;
     }
     if ((rc = fill(v)) != TSDF_OK) return cleanup(rc);
     *out = v;
@@ -1094,19 +1173,13 @@ int tsdf_destroy(tsdf_volume *v)
     if (v->stream && v->stream != v->own_stream) (void)hipStreamSynchronize(v->stream);
     if (v->copy_stream) (void)hipStreamSynchronize(v->copy_stream);
     v->pend_count = 0;   // frames collected but never observed: nothing can tell whether they were applied
-    for (int i = 0; i < 2; ++i) {
-        if (v->d_pool[i]) (void)hipFree(v->d_pool[i]);
-        if (v->d_mask_pool[i]) (void)hipFree(v->d_mask_pool[i]);
-        if (v->pool_done[i]) (void)hipEventDestroy(v->pool_done[i]);
+    if (v->store) {      // (the streams are idle: whatever this handle held, or others were waiting on its events for, is free)
+        tsdf_store::slots_drop_owner(v->store, v);
+        tsdf_store::store_unref(v->store);
+        v->store = nullptr;
     }
     if (v->pend_copied) (void)hipEventDestroy(v->pend_copied);
-    for (int i = 0; i < kStageSlots; ++i) {
-        if (v->copy_done[i]) (void)hipEventDestroy(v->copy_done[i]);
-        if (v->stage_done[i]) (void)hipEventDestroy(v->stage_done[i]);
-        if (v->h_stage[i]) (void)hipHostFree(v->h_stage[i]);
-        if (v->d_stage[i]) (void)hipFree(v->d_stage[i]);
-        if (v->d_raw[i]) (void)hipFree(v->d_raw[i]);
-    }
+    if (v->flush_done) (void)hipEventDestroy(v->flush_done);
     for (int i = 0; i < kStageSlots; ++i) {
         if (v->h_frames[i]) (void)hipHostFree(v->h_frames[i]);
         if (v->d_frames[i]) (void)hipFree(v->d_frames[i]);
@@ -1116,6 +1189,7 @@ int tsdf_destroy(tsdf_volume *v)
     for (int i = 0; i < kStageSlots; ++i) {
         if (v->d_rgb[i]) (void)hipFree(v->d_rgb[i]);
         if (v->h_rgb[i]) (void)hipHostFree(v->h_rgb[i]);
+        if (v->rgb_done[i]) (void)hipEventDestroy(v->rgb_done[i]);
     }
     if (v->d_label) (void)hipFree(v->d_label);
     if (v->d_fp) (void)hipFree(v->d_fp);
@@ -1124,7 +1198,6 @@ int tsdf_destroy(tsdf_volume *v)
     if (v->d_list) (void)hipFree(v->d_list);
     if (v->d_wg_class) (void)hipFree(v->d_wg_class);
     if (v->d_flags) (void)hipFree(v->d_flags);
-    if (v->d_tiles) (void)hipFree(v->d_tiles);
     if (v->d_super) (void)hipFree(v->d_super);
     if (v->d_work) (void)hipFree(v->d_work);
     if (v->d_claims) (void)hipFree(v->d_claims);
@@ -1153,36 +1226,27 @@ int tsdf_integrate(tsdf_volume *v, const float *depth_host, const float cam2worl
     const bool defer = v->defer_n > 1;
     int rc = bind_device(v, !defer);
     if (rc) return rc;
-    const int s = v->stage_next;
-    v->stage_next = (s + 1) % kStageSlots;
-    // the pinned slot is free when its last copy has run (deferred calls) and its last kernel has (immediate calls)
-    if (v->copy_used[s]) HIP_TRY(hipEventSynchronize(v->copy_done[s]));
-    if (v->stage_used[s]) HIP_TRY(hipEventSynchronize(v->stage_done[s]));
-    const size_t px = (size_t)v->cfg.im_height * v->cfg.im_width, img = px * sizeof(float);
-    std::memcpy(v->h_stage[s], depth_host, img);  // caller may free depth_host after we return
+    const size_t img = (size_t)v->cfg.im_height * v->cfg.im_width * sizeof(float);
+    // caller's frame -> pinned ring -> a frame slot in HBM (copy stream); the caller may free depth_host when we return
+    int slot = -1;
+    void *dev = nullptr;
+    rc = stage_begin(v, img, [&](float *pinned) { std::memcpy(pinned, depth_host, img); }, &slot, &dev);
+    if (rc) return rc;
     if (defer) {
-        // collect: frame into the pool being filled, pose composed now; launched defer_n at a time (or at the next
-        // call that observes the volume) as one fused sequence
-        float *dst = nullptr;
-        rc = pool_slot_begin(v, &dst);
-        if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(dst, v->h_stage[s], img, hipMemcpyHostToDevice, v->copy_stream));
-        HIP_TRY(hipEventRecord(v->copy_done[s], v->copy_stream));
-        v->copy_used[s] = true;
-        return pool_slot_commit(v, cam2world);
+        // collect: pose composed now; launched defer_n at a time (or at the next call that observes the volume) as one fused
+        // sequence
+        Collected c;
+        c.slot = slot; c.mask_slot = -1; c.dev = static_cast<float *>(dev); c.mask = nullptr;
+        return pool_slot_commit(v, c, cam2world);
     }
-    // copy on the copy stream (it overlaps the kernel of the previous frame), kernel after it
-    HIP_TRY(hipMemcpyAsync(v->d_stage[s], v->h_stage[s], img, hipMemcpyHostToDevice, v->copy_stream));
-    HIP_TRY(hipEventRecord(v->copy_done[s], v->copy_stream));
-    v->copy_used[s] = true;
-    HIP_TRY(hipStreamWaitEvent(v->stream, v->copy_done[s], 0));
+    // one kernel per call: it waits for the copy (which overlapped the previous frame's kernel)
+    rc = stream_waits_for_copies(v);
+    if (rc) return rc;
     float c2b[16];
     compose_cam2base(v, cam2world, c2b);
-    rc = launch_integrate(v, v->d_stage[s], nullptr, c2b);
+    rc = launch_integrate(v, static_cast<const float *>(dev), nullptr, c2b);
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(v->stage_done[s], v->stream));
-    v->stage_used[s] = true;
-    return TSDF_OK;
+    return stage_end(v, &slot, 1);
 }
 
 int tsdf_set_deferral(tsdf_volume *v, int32_t n_frames)
@@ -1221,39 +1285,33 @@ int tsdf_integrate_u16(tsdf_volume *v, const uint16_t *raw_host, float depth_fac
     const bool defer = v->defer_n > 1;
     int rc = bind_device(v, !defer);
     if (rc) return rc;
-    const int s = v->stage_next;
-    v->stage_next = (s + 1) % kStageSlots;
-    if (v->copy_used[s]) HIP_TRY(hipEventSynchronize(v->copy_done[s]));
-    if (v->stage_used[s]) HIP_TRY(hipEventSynchronize(v->stage_done[s]));
     const size_t px = (size_t)v->cfg.im_height * v->cfg.im_width;
-    if (!v->d_raw[s]) HIP_TRY(hipMalloc((void **)&v->d_raw[s], px * sizeof(uint16_t)));
-    std::memcpy(v->h_stage[s], raw_host, px * sizeof(uint16_t));  // the float-sized pinned slot holds it
-    HIP_TRY(hipMemcpyAsync(v->d_raw[s], v->h_stage[s], px * sizeof(uint16_t), hipMemcpyHostToDevice, v->copy_stream));
-    if (defer) {
-        // collected like tsdf_integrate's frames: converted on the copy stream straight into the pool slot
-        float *dst = nullptr;
-        rc = pool_slot_begin(v, &dst);
-        if (rc) return rc;
-        const int n = (int)px;
-        hipLaunchKernelGGL(tsdfk::depth_u16_to_f32, dim3((n + 255) / 256), dim3(256), 0, v->copy_stream, v->d_raw[s], dst,
-                           v->cfg.im_height, v->cfg.im_width, 1.0f / depth_factor, row_step, col_step);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(v->copy_done[s], v->copy_stream));   // covers the copy and the conversion that read d_raw[s]
-        v->copy_used[s] = true;
-        return pool_slot_commit(v, cam2world);
-    }
-    HIP_TRY(hipEventRecord(v->copy_done[s], v->copy_stream));
-    v->copy_used[s] = true;
-    HIP_TRY(hipStreamWaitEvent(v->stream, v->copy_done[s], 0));
-    rc = tsdf_convert_depth_u16(v, v->d_raw[s], v->d_stage[s], depth_factor, row_step, col_step);
+    // the raw frame (half the bytes of the float frame) -> pinned ring -> a frame slot; converted on the copy stream into a
+    // second slot, which is the frame Integrate reads
+    int raw_slot = -1, slot = -1;
+    void *raw_dev = nullptr, *dev = nullptr;
+    rc = stage_begin(v, px * sizeof(uint16_t), [&](float *pinned) { std::memcpy(pinned, raw_host, px * sizeof(uint16_t)); }, &raw_slot, &raw_dev);
     if (rc) return rc;
+    rc = store_slot(v, &v->store->frames, v->copy_stream, &slot, &dev);
+    if (rc) return rc;
+    hipLaunchKernelGGL(tsdfk::depth_u16_to_f32, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, v->copy_stream,
+                       static_cast<const uint16_t *>(raw_dev), static_cast<float *>(dev), v->cfg.im_height, v->cfg.im_width,
+                       1.0f / depth_factor, row_step, col_step);   // ref: examples/label_instance_rgbd.cpp:99-100 (fp32 reciprocal)
+    HIP_TRY(hipGetLastError());
+    // the raw slot is free once the conversion has run: released after an event of the copy stream
+    HIP_TRY(hipEventRecord(v->pend_copied, v->copy_stream));
+    tsdf_store::slots_release_after(v->store, &v->store->frames, &raw_slot, 1, &v->pend_copied, v);
+    if (defer) {
+        Collected c;
+        c.slot = slot; c.mask_slot = -1; c.dev = static_cast<float *>(dev); c.mask = nullptr;
+        return pool_slot_commit(v, c, cam2world);
+    }
+    HIP_TRY(hipStreamWaitEvent(v->stream, v->pend_copied, 0));
     float c2b[16];
     compose_cam2base(v, cam2world, c2b);
-    rc = launch_integrate(v, v->d_stage[s], nullptr, c2b);
+    rc = launch_integrate(v, static_cast<const float *>(dev), nullptr, c2b);
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(v->stage_done[s], v->stream));
-    v->stage_used[s] = true;
-    return TSDF_OK;
+    return stage_end(v, &slot, 1);
 }
 
 int tsdf_integrate_device(tsdf_volume *v, const float *depth_dev, const float cam2world[16])
@@ -1908,30 +1966,33 @@ int tsdf_integrate_rgbd(tsdf_volume *v, const float *depth_host, const uint8_t *
     if (!v->d_colour) return fail(TSDF_ERR_INVALID, "tsdf_integrate_rgbd: call tsdf_colour_enable first");
     int rc = bind_device(v);
     if (rc) return rc;
-    const int s = v->stage_next;
-    v->stage_next = (s + 1) % kStageSlots;
-    if (v->copy_used[s]) HIP_TRY(hipEventSynchronize(v->copy_done[s]));
-    if (v->stage_used[s]) HIP_TRY(hipEventSynchronize(v->stage_done[s]));
     const size_t px = (size_t)v->cfg.im_height * v->cfg.im_width, img = px * sizeof(float);
+    // the colour image has a small ring of its own (pinned + HBM, allocated on first use; one event per slot: the colour
+    // kernel that read it), the depth frame goes through the shared store like any other host frame
+    const int s = v->rgb_next;
+    v->rgb_next = (s + 1) % kStageSlots;
     if (!v->d_rgb[s]) {
         HIP_TRY(hipMalloc((void **)&v->d_rgb[s], px * 3));
         HIP_TRY(hipHostMalloc((void **)&v->h_rgb[s], px * 3, hipHostMallocDefault));
+        HIP_TRY(hipEventCreateWithFlags(&v->rgb_done[s], hipEventDisableTiming));
     }
-    std::memcpy(v->h_stage[s], depth_host, img);   // the caller may free both images after we return
-    std::memcpy(v->h_rgb[s], rgb_host, px * 3);
-    HIP_TRY(hipMemcpyAsync(v->d_stage[s], v->h_stage[s], img, hipMemcpyHostToDevice, v->copy_stream));
+    if (v->rgb_used[s]) HIP_TRY(hipEventSynchronize(v->rgb_done[s]));
+    std::memcpy(v->h_rgb[s], rgb_host, px * 3);           // the caller may free both images after we return
+    int slot = -1;
+    void *dev = nullptr;
+    rc = stage_begin(v, img, [&](float *pinned) { std::memcpy(pinned, depth_host, img); }, &slot, &dev);
+    if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(v->d_rgb[s], v->h_rgb[s], px * 3, hipMemcpyHostToDevice, v->copy_stream));
-    HIP_TRY(hipEventRecord(v->copy_done[s], v->copy_stream));
-    v->copy_used[s] = true;
-    HIP_TRY(hipStreamWaitEvent(v->stream, v->copy_done[s], 0));
+    rc = stream_waits_for_copies(v);
+    if (rc) return rc;
     float c2b[16];
     compose_cam2base(v, cam2world, c2b);
-    rc = launch_integrate(v, v->d_stage[s], nullptr, c2b);
-    if (rc == TSDF_OK) rc = launch_colour(v, v->d_stage[s], v->d_rgb[s], c2b);
+    rc = launch_integrate(v, static_cast<const float *>(dev), nullptr, c2b);
+    if (rc == TSDF_OK) rc = launch_colour(v, static_cast<const float *>(dev), v->d_rgb[s], c2b);
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(v->stage_done[s], v->stream));
-    v->stage_used[s] = true;
-    return TSDF_OK;
+    HIP_TRY(hipEventRecord(v->rgb_done[s], v->stream));
+    v->rgb_used[s] = true;
+    return stage_end(v, &slot, 1);
 }
 
 int tsdf_download_colour(tsdf_volume *v, uint32_t *colour_host)
@@ -1966,7 +2027,7 @@ int batch_flush(tsdf_batch *b)
     // fork: the side streams start when everything queued on the batch's stream so far (the frames' copies) is done
     // (measured, 200^3 members with instance masks, ms per frame, one stream -> four: 16 members 0.081 -> 0.062, 8 members
     // 0.047 -> 0.045, 4 members 0.027 -> 0.034, 2 members 0.016 -> 0.023: few members fill the GPU one after the other)
-    const int lanes = (std::getenv("TSDF_BATCH_SERIAL") || members < 8) ? 1 : kBatchSideStreams;
+    const int lanes = members < 8 ? 1 : kBatchSideStreams;
     hipError_t e = hipSuccess;
     if (rc == TSDF_OK && lanes > 1) {
         if (!b->collected) {

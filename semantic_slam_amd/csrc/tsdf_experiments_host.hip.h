@@ -48,8 +48,9 @@ void launch_ladder(const tsdf_volume *v, const tsdfk::IntegrateParams &p)
 // (grid nbx x nby x nz; rows_per_wg as classify_workgroups takes it).  Sets p.wg_class.
 int classify_single(tsdf_volume *v, tsdfk::IntegrateParams &p, int nbx, int nby, int nz, int rows_per_wg)
 {
-    const size_t per = tile_table_elems_host(p.tiles_w, p.tiles_h);
-    if (!v->d_tiles) HIP_TRY(hipMalloc((void **)&v->d_tiles, tsdfk::kMaxFramesPerLaunch * per * sizeof(float2)));
+    float2 *tiles = nullptr;
+    int rc0 = tables_begin(v, &tiles);   // (released by the caller's tables_end() after the launch that reads the classes)
+    if (rc0) return rc0;
     const size_t n_wg = (size_t)nbx * nby * nz;
     if (v->wg_class_bytes < n_wg) {
         if (v->d_wg_class) HIP_TRY(hipFree(v->d_wg_class));
@@ -60,11 +61,11 @@ int classify_single(tsdf_volume *v, tsdfk::IntegrateParams &p, int nbx, int nby,
     }
     const float *d = p.depth;
     const uint8_t *m = p.mask;
-    int rc = build_tile_tables(v->stream, v->cfg, p, &d, &m, 1, v->d_tiles);
+    int rc = build_tile_tables(v->stream, v->cfg, p, &d, &m, 1, tiles);
     if (rc) return rc;
     tsdfk::FramePose pose;
     pose_from_params(pose, p);
-    pose.tiles = v->d_tiles;
+    pose.tiles = tiles;
     hipLaunchKernelGGL(tsdfk::classify_workgroups, dim3((unsigned)((n_wg + 255) / 256)), dim3(256), 0, v->stream, p, pose,
                        v->d_wg_class, nbx, nby, nz, rows_per_wg);
     HIP_TRY(hipGetLastError());
@@ -88,7 +89,7 @@ int launch_integrate_experiment(tsdf_volume *v, const float *depth_dev, const ui
         if (rc) return rc;
         hipLaunchKernelGGL((tsdfk::ladder_tile<2, true, true, true, true, false, true, false, true>), grid, dim3(64, 4, 1), 0, v->stream, p);
         HIP_TRY(hipGetLastError());
-        return TSDF_OK;
+        return tables_end(v);
     }
     // which launches keep the free-space summary up to date: the SUM kernels; the rows kernel and the plain tile variants do not
     const bool summary = variant != 2 && ((variant >= 32 && variant < 64) || (variant >= 80 && variant < 96) || variant >= 112);
@@ -161,7 +162,7 @@ int launch_single_experiment(tsdf_volume *v, tsdfk::IntegrateParams &common, tsd
     hipLaunchKernelGGL((tsdfk::integrate_multi_single_cls<true, true, true>), grid, block, 0, v->stream, common, pose);
     HIP_TRY(hipGetLastError());
     *handled = true;
-    return TSDF_OK;
+    return tables_end(v);
 }
 
 // Fused launches of the measurement build: staged frame blocks (4, 5, 6), rows classified per workgroup (11), brick

@@ -26,6 +26,8 @@ struct tsdf_group {
     // pinned frames every device can read (hipHostMallocPortable): a ring for single frames, a pool for sequences
     float *h_ring[kStageSlots];
     int ring_next;
+    std::vector<hipEvent_t> ring_copied;  // [ring slot][slab]: that slab's copy out of the slot
+    std::vector<bool> ring_used;
     float *h_pool;                        // kMaxFramesPerLaunch frames, allocated on first tsdf_group_integrate_frames
     std::vector<float *> d_pool;          // per slab: the same frames in its device's memory
     std::vector<hipEvent_t> pool_done;    // per slab: the copy of its last pass out of h_pool has run
@@ -83,8 +85,6 @@ int fetch_halo(tsdf_group *g, int i, const float **ht, const float **hw)
 enum class ListKind { Surface, Crossings, Mesh };
 
 // count pass on every slab (concurrently), then -- when a destination is given -- the emit passes into the right offsets
-int group_flush(tsdf_group *g);
-
 int group_list(tsdf_group *g, ListKind kind, float weight_thresh, float *out_host, int64_t capacity, int64_t *count)
 {
     int rc_flush = group_flush(g);
@@ -155,6 +155,7 @@ int group_wait_pool(tsdf_group *g)
     return TSDF_OK;
 }
 
+// (called by every group entry point and, through bind_device, by every entry point of a borrowed slab handle)
 int group_flush(tsdf_group *g)
 {
     if (g->pend_count == 0) return TSDF_OK;
@@ -173,6 +174,7 @@ int tsdf_group_destroy(tsdf_group *g)
     for (size_t i = 0; i < g->slabs.size(); ++i) {
         tsdf_volume *v = g->slabs[i];
         if (!v) continue;
+        v->group_owner = nullptr;     // frames collected but never observed go with the group
         (void)hipSetDevice(v->cfg.device);
         (void)hipStreamSynchronize(v->stream);
         if (i < g->d_pool.size() && g->d_pool[i]) (void)hipFree(g->d_pool[i]);
@@ -180,6 +182,8 @@ int tsdf_group_destroy(tsdf_group *g)
         if (i < g->d_halo.size() && g->d_halo[i]) (void)hipFree(g->d_halo[i]);
         tsdf_destroy(v);
     }
+    for (hipEvent_t e : g->ring_copied)
+        if (e) (void)hipEventDestroy(e);
     for (int s = 0; s < kStageSlots; ++s)
         if (g->h_ring[s]) (void)hipHostFree(g->h_ring[s]);
     if (g->h_pool) (void)hipHostFree(g->h_pool);
@@ -213,6 +217,7 @@ int tsdf_group_create(const tsdf_config *cfg, const int32_t *devices, int32_t n_
         tsdf_volume *v = nullptr;
         int rc = tsdf_create(&c, &v);
         if (rc) return cleanup(rc);
+        v->group_owner = g;           // every entry point of the slab's handle applies the group's collected frames first
         g->slabs.push_back(v);
         g->devices.push_back(devices[i]);
     }
@@ -220,6 +225,8 @@ int tsdf_group_create(const tsdf_config *cfg, const int32_t *devices, int32_t n_
     g->pool_done.assign((size_t)n_slabs, nullptr);
     g->pool_used.assign((size_t)n_slabs, false);
     g->d_halo.assign((size_t)n_slabs, nullptr);
+    g->ring_copied.assign((size_t)n_slabs * kStageSlots, nullptr);
+    g->ring_used.assign((size_t)n_slabs * kStageSlots, false);
     const size_t img = (size_t)cfg->im_height * cfg->im_width * sizeof(float);
     for (int s = 0; s < kStageSlots; ++s) {
         hipError_t e = hipHostMalloc((void **)&g->h_ring[s], img, hipHostMallocPortable);
@@ -251,8 +258,8 @@ int64_t tsdf_group_voxels(const tsdf_group *g)
 int tsdf_group_volume(tsdf_group *g, int32_t i, tsdf_volume **vol)
 {
     if (!g || !vol || i < 0 || i >= (int)g->slabs.size()) return fail(TSDF_ERR_INVALID, "tsdf_group_volume: bad argument");
-    int rc = group_flush(g);       // whoever borrows a slab sees every frame handed to the group so far
-    if (rc) return rc;
+    int rc = group_flush(g);       // (the handle's own entry points do this too: frames given to the group later are applied
+    if (rc) return rc;             //  before anything observes or integrates through the borrowed handle)
     *vol = g->slabs[(size_t)i];
     return TSDF_OK;
 }
@@ -273,27 +280,35 @@ int tsdf_group_integrate(tsdf_group *g, const float *depth_host, const float cam
     const int s = g->ring_next;
     g->ring_next = (s + 1) % kStageSlots;
     const size_t img = (size_t)g->cfg.im_height * g->cfg.im_width * sizeof(float);
-    // the pinned slot is free again when every slab's copy out of it has run: the slabs' own slot events say so
-    for (tsdf_volume *v : g->slabs) {
-        if (v->stage_used[s]) {
-            HIP_TRY(hipSetDevice(v->cfg.device));
-            HIP_TRY(hipEventSynchronize(v->stage_done[s]));
+    const size_t n = g->slabs.size();
+    // the pinned slot is free again when every slab's copy out of it has run
+    for (size_t i = 0; i < n; ++i) {
+        if (g->ring_used[(size_t)s * n + i]) {
+            HIP_TRY(hipSetDevice(g->slabs[i]->cfg.device));
+            HIP_TRY(hipEventSynchronize(g->ring_copied[(size_t)s * n + i]));
         }
     }
     std::memcpy(g->h_ring[s], depth_host, img);          // the caller may free depth_host after we return
-    for (tsdf_volume *v : g->slabs) {
+    for (size_t i = 0; i < n; ++i) {
+        tsdf_volume *v = g->slabs[i];
         int rc0 = bind_device(v);      // device current; frames given to a borrowed slab handle come first
         if (rc0) return rc0;
-        HIP_TRY(hipMemcpyAsync(v->d_stage[s], g->h_ring[s], img, hipMemcpyHostToDevice, v->copy_stream));
-        HIP_TRY(hipEventRecord(v->copy_done[s], v->copy_stream));
-        HIP_TRY(hipStreamWaitEvent(v->stream, v->copy_done[s], 0));
+        // a frame slot of the slab's store, filled on its copy stream (overlapping the slab's previous kernel)
+        int slot = -1;
+        void *dev = nullptr;
+        int rc = store_slot(v, &v->store->frames, v->copy_stream, &slot, &dev);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(dev, g->h_ring[s], img, hipMemcpyHostToDevice, v->copy_stream));
+        if (!g->ring_copied[(size_t)s * n + i]) HIP_TRY(hipEventCreateWithFlags(&g->ring_copied[(size_t)s * n + i], hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(g->ring_copied[(size_t)s * n + i], v->copy_stream));
+        g->ring_used[(size_t)s * n + i] = true;
+        HIP_TRY(hipStreamWaitEvent(v->stream, g->ring_copied[(size_t)s * n + i], 0));
         float c2b[16];
         compose_cam2base(v, cam2world, c2b);
-        int rc = launch_integrate(v, v->d_stage[s], nullptr, c2b);
+        rc = launch_integrate(v, static_cast<const float *>(dev), nullptr, c2b);
         if (rc) return rc;
-        HIP_TRY(hipEventRecord(v->stage_done[s], v->stream));
-        v->stage_used[s] = true;
-        v->stage_next = (s + 1) % kStageSlots;           // keep the handle's own ring in step (tsdf_integrate on a borrowed slab)
+        rc = stage_end(v, &slot, 1);
+        if (rc) return rc;
     }
     return TSDF_OK;
 }

@@ -95,3 +95,48 @@ def test_group_deferral(cuda, oracle, defer):
                 assert len(grp.extract_surface()) == len(oracle.surface_points(ref_t, ref_w, dims, vs, origin))
         t, w = grp.download()
     assert np.array_equal(w, ref_w) and np.array_equal(t.view(np.uint32), ref_t.view(np.uint32))
+
+
+def test_many_object_handles_share_one_frame_store(cuda, oracle):
+    """The reference keeps one TSDF per object instance (ref: src/Object.cpp:67, src/Engine.cpp:172-233 creates them by the
+    dozen).  Staging, deferral and tile-table memory is one store per device and image size (csrc/frame_store.h), not
+    per handle: 64 handles of 64^3 voxels (2 MB each), each fed host frames through the reference's own call, must cost far
+    less than the 64 x ~105 MB of per-handle pools they used to -- asserted on hipMemGetInfo -- and every one must still equal
+    the oracle.  More frames are collected (64 x 5 = 320) than the store's soft cap holds (160 slots), so handles also
+    flush themselves to make room."""
+    dims, vs = (64, 64, 64), 0.0125
+    n_obj, n_frames = 64, 5
+    scene = synth.SurfScene((200, 200, 200), 0.004, np.array([-0.4, -0.4, 0.7], np.float32))
+    poses = [scene.pose(k, 7) for k in range(n_frames)]
+    depths = [scene.depth(p, quantize=True) for p in poses]
+    rng = np.random.default_rng(64)
+    origins = [np.array([-0.5 + rng.uniform(0, 0.3), -0.5 + rng.uniform(0, 0.3), 0.7 + rng.uniform(0, 0.4)], np.float32) for _ in range(n_obj)]
+    cfgs = [capi.make_config(dims, vs, o, vol_id=i) for i, o in enumerate(origins)]
+    cuda.cuda.synchronize()
+    free0, _ = cuda.cuda.mem_get_info()
+    vols = [capi.Volume(c) for c in cfgs]
+    try:
+        for k in range(n_frames):                 # the caller's loop: every object gets every keyframe (its own masked copy)
+            for i, vol in enumerate(vols):
+                d = depths[k].copy()
+                d[:, : 10 * (i % 8)] = 0.0        # a different frame per object, as depth x its instance mask would be
+                vol.integrate(d, poses[k])
+        for vol in vols:
+            vol.sync()
+        free1, _ = cuda.cuda.mem_get_info()
+        used = free0 - free1
+        volumes = n_obj * 2 * 4 * dims[0] * dims[1] * dims[2]
+        # volumes + summaries + one shared store (<= 160 frame slots of 1.2 MB + tables + lists); the per-handle pools of round 2
+        # would be 64 x (7.4 + 78.6 + 9.4) MB = 6.1 GB
+        assert used < volumes + 600 * 2 ** 20, f"{used / 2 ** 20:.0f} MiB in use for {volumes / 2 ** 20:.0f} MiB of volumes"
+        for i, vol in enumerate(vols):
+            rt, rw = oracle.init_grid(dims)
+            for k in range(n_frames):
+                d = depths[k].copy()
+                d[:, : 10 * (i % 8)] = 0.0
+                oracle.integrate(cfgs[i].cam_K, poses[k], d, dims, origins[i], vs, cfgs[i].trunc_margin, rt, rw)
+            t, w = vol.download()
+            assert np.array_equal(w, rw) and np.array_equal(t.view(np.uint32), rt.view(np.uint32)), f"object {i}"
+    finally:
+        for vol in vols:
+            vol.close()

@@ -102,3 +102,45 @@ def test_cpp_class_over_a_device_list(cuda, oracle, tmp_path):
         assert a == b and len(a) > 1000, ext
     oracle.save_bin(str(tmp_path / "o.bin"), ref_t, dims, origin, vs, cfg.trunc_margin)
     assert open(str(tmp_path / "o.bin"), "rb").read() == open(str(tmp_path / "tsdf2.bin"), "rb").read()
+
+
+def test_borrowed_slab_handle_sees_the_groups_collected_frames_in_call_order(cuda, oracle):
+    """tsdf_group_integrate collects frames (deferred integration, 32 per pass).  A slab handle borrowed with
+    tsdf_group_volume must see them: observing through it (download, extraction, device pointers) applies them first,
+    and a frame integrated through it AFTER group frames is applied after them -- the float bits depend on the order."""
+    dims, vs = (128, 48, 30), 0.012
+    origin = synth.surf_volume(dims[0], vs, 0.8)
+    cfg = capi.make_config(dims, vs, origin)
+    frames = scene_frames(dims, vs, origin, 8)
+    with capi.Group(cfg, [0, 0]) as grp:            # (capi.Group borrows every slab in its constructor, before any frame)
+        lo = grp.slabs[0]
+        zb, ze = lo.cfg.z_begin, lo.cfg.z_end
+        rt, rw = oracle.init_grid(dims, zb, ze)
+
+        def ref(k):
+            oracle.integrate(cfg.cam_K, frames[k][0], frames[k][1], dims, origin, vs, cfg.trunc_margin, rt, rw, z_begin=zb, z_end=ze)
+
+        for k in range(3):                           # collected by the group, not yet launched
+            grp.integrate(frames[k][1], frames[k][0])
+            ref(k)
+        t, w = lo.download()                         # observation through the borrowed handle
+        assert rw.max() >= 3
+        assert np.array_equal(w, rw) and np.array_equal(t.view(np.uint32), rt.view(np.uint32))
+        grp.integrate(frames[3][1], frames[3][0])    # group frame A (collected) ...
+        ref(3)
+        d_dev = cuda.from_numpy(frames[4][1]).cuda()
+        lo.integrate_device(d_dev.data_ptr(), frames[4][0])   # ... then frame B through the slab handle: A first, then B
+        ref(4)
+        grp.integrate(frames[5][1], frames[5][0])    # ... then group frame C: B (collected by the slab) first, then C
+        ref(5)
+        assert lo.count_surface() > 100              # an extraction through the handle applies all three
+        t, w = lo.download()
+        assert np.array_equal(w, rw) and np.array_equal(t.view(np.uint32), rt.view(np.uint32))
+        # the other slab saw the group's frames only (0, 1, 2, 3, 5)
+        hi = grp.slabs[1]
+        ht, hw = oracle.init_grid(dims, hi.cfg.z_begin, hi.cfg.z_end)
+        for k in (0, 1, 2, 3, 5):
+            oracle.integrate(cfg.cam_K, frames[k][0], frames[k][1], dims, origin, vs, cfg.trunc_margin, ht, hw,
+                             z_begin=hi.cfg.z_begin, z_end=hi.cfg.z_end)
+        t, w = hi.download()
+        assert np.array_equal(w, hw) and np.array_equal(t.view(np.uint32), ht.view(np.uint32))
