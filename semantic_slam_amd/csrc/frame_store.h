@@ -25,13 +25,14 @@ namespace tsdf_store {
 
 constexpr int kRingSlots = 4;
 constexpr int kSoftCapFrames = 160;    // frame slots (197 MB at 640 x 480) before collecting handles are asked to flush themselves
-constexpr int kSoftCapTables = 6;      // table slots: launches of that many handles may overlap before one waits for another's
+constexpr int kSoftCapTables = 16;     // table slots (9.2 MB each at 640 x 480): launches of that many handles may be in flight before one waits for another's
 
 struct Slot {
     void *dev;
     hipEvent_t *release;     // state 2: free again once this event (owned by the handle that used the slot) has happened
     const void *owner;       // the handle holding it (state 1) or whose event it waits for (state 2)
     int state;               // 0 free, 1 held, 2 in flight
+    unsigned long long seq;  // state 2: when it was released (the class's counter): the oldest is reused first
 };
 
 struct RingSlot {
@@ -44,6 +45,8 @@ struct SlotClass {
     std::vector<Slot> slots;
     size_t bytes;
     int soft_cap;
+    int quota;               // slots one handle may take before it reuses its own (stream-ordered) instead of growing the class
+    unsigned long long seq;
 };
 
 struct FrameStore {
@@ -54,6 +57,7 @@ struct FrameStore {
     RingSlot ring[kRingSlots];
     int ring_next;
     SlotClass frames, masks, tables;
+    hipStream_t copy_stream;   // host -> device copies of every handle of the store (one PCIe pipe; a stream per handle cost ~2 MiB each)
 };
 
 inline std::mutex &registry_mutex() { static std::mutex m; return m; }
@@ -67,10 +71,15 @@ inline hipError_t store_ref(int device, size_t px, size_t table_bytes, FrameStor
         if (s->device == device && s->px == px && s->tables.bytes == table_bytes) { ++s->refs; *out = s; return hipSuccess; }
     FrameStore *s = new FrameStore();
     s->device = device; s->px = px; s->refs = 1; s->ring_next = 0;
-    s->frames.bytes = px * sizeof(float); s->frames.soft_cap = kSoftCapFrames;
-    s->masks.bytes = px; s->masks.soft_cap = kSoftCapFrames;
-    s->tables.bytes = table_bytes; s->tables.soft_cap = kSoftCapTables;
+    s->frames.seq = s->masks.seq = s->tables.seq = 0;
+    s->frames.bytes = px * sizeof(float); s->frames.soft_cap = kSoftCapFrames; s->frames.quota = 64;
+    s->masks.bytes = px; s->masks.soft_cap = kSoftCapFrames; s->masks.quota = 64;
+    s->tables.bytes = table_bytes; s->tables.soft_cap = kSoftCapTables; s->tables.quota = 2;
+    s->copy_stream = nullptr;
     for (int i = 0; i < kRingSlots; ++i) { s->ring[i].host = nullptr; s->ring[i].copied = nullptr; s->ring[i].used = s->ring[i].busy = false; }
+    (void)hipSetDevice(device);
+    const hipError_t e = hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete s; return e; }
     registry().push_back(s);
     *out = s;
     return hipSuccess;
@@ -82,6 +91,7 @@ inline void store_unref(FrameStore *s)
     std::lock_guard<std::mutex> lk(registry_mutex());
     if (--s->refs > 0) return;
     (void)hipSetDevice(s->device);
+    if (s->copy_stream) { (void)hipStreamSynchronize(s->copy_stream); (void)hipStreamDestroy(s->copy_stream); }
     for (int i = 0; i < kRingSlots; ++i) {
         if (s->ring[i].copied) { (void)hipEventSynchronize(s->ring[i].copied); (void)hipEventDestroy(s->ring[i].copied); }
         if (s->ring[i].host) (void)hipHostFree(s->ring[i].host);
@@ -130,34 +140,39 @@ inline hipError_t ring_release(FrameStore *s, int i, hipStream_t stream)
     return e;
 }
 
-// A slot of class c for `owner`, whose first access will be queued on `first_user`.  *index = -1 with hipSuccess: the class is at
-// its soft cap and every slot is held by handles that are still collecting -- the caller should apply its own collected frames
-// and ask again with force = true.
+// A slot of class c for `owner`, whose first access will be queued on `first_user`.  In order of preference: a free slot; once
+// the handle has its quota (two passes' worth: one being filled while the other is read), the slot it released longest ago --
+// its stream waits for its own earlier launch; a new slot while the class is below its soft cap (rather than make one handle's
+// launch wait for another's); the slot released longest ago by anyone -- the next user's stream waits for that reader, the host
+// never does (and no hipEventQuery: it costs microseconds per call on this runtime).  *index = -1 with hipSuccess: at the cap
+// with every slot HELD by handles that are still collecting -- the caller should apply its own collected frames and ask again
+// with force = true.
 inline hipError_t slot_acquire(FrameStore *s, SlotClass *c, const void *owner, hipStream_t first_user, bool force, int *index, void **dev)
 {
     std::lock_guard<std::mutex> lk(s->mu);
     *index = -1;
-    int pick = -1;
-    for (size_t i = 0; i < c->slots.size() && pick < 0; ++i) if (c->slots[i].state == 0) pick = (int)i;
-    if (pick < 0) {
-        // in flight: prefer one whose event has already happened, else any (its next user's stream waits)
-        int any = -1;
-        for (size_t i = 0; i < c->slots.size(); ++i) {
-            if (c->slots[i].state != 2) continue;
-            if (any < 0) any = (int)i;
-            if (hipEventQuery(*c->slots[i].release) == hipSuccess) { pick = (int)i; break; }
-        }
-        (void)hipGetLastError();   // "not ready" is an answer
-        if (pick < 0) pick = any;
-        if (pick >= 0) {
-            const hipError_t e = hipStreamWaitEvent(first_user, *c->slots[(size_t)pick].release, 0);
-            if (e != hipSuccess) return e;
-        }
+    int pick = -1, mine = -1, oldest = -1, own = 0;
+    for (size_t i = 0; i < c->slots.size(); ++i) {
+        const Slot &x = c->slots[i];
+        if (x.state == 0) { if (pick < 0) pick = (int)i; continue; }
+        if (x.owner == owner) ++own;
+        if (x.state != 2) continue;
+        if (x.owner == owner && (mine < 0 || x.seq < c->slots[(size_t)mine].seq)) mine = (int)i;
+        if (oldest < 0 || x.seq < c->slots[(size_t)oldest].seq) oldest = (int)i;
+    }
+    const bool at_cap = (int)c->slots.size() >= c->soft_cap;
+    int wait_for = -1;
+    if (pick < 0 && mine >= 0 && (own >= c->quota || at_cap)) wait_for = mine;
+    else if (pick < 0 && at_cap && oldest >= 0) wait_for = oldest;
+    if (wait_for >= 0) {
+        const hipError_t e = hipStreamWaitEvent(first_user, *c->slots[(size_t)wait_for].release, 0);
+        if (e != hipSuccess) return e;
+        pick = wait_for;
     }
     if (pick < 0) {
-        if ((int)c->slots.size() >= c->soft_cap && !force) return hipSuccess;
+        if (at_cap && !force) return hipSuccess;
         Slot x;
-        x.dev = nullptr; x.release = nullptr; x.owner = nullptr; x.state = 0;
+        x.dev = nullptr; x.release = nullptr; x.owner = nullptr; x.state = 0; x.seq = 0;
         const hipError_t e = hipMalloc(&x.dev, c->bytes ? c->bytes : 1);
         if (e != hipSuccess) return e;
         c->slots.push_back(x);
@@ -178,7 +193,7 @@ inline void slots_release_after(FrameStore *s, SlotClass *c, const int *idx, int
     for (int k = 0; k < n; ++k) {
         if (idx[k] < 0) continue;
         Slot &x = c->slots[(size_t)idx[k]];
-        x.state = 2; x.release = release; x.owner = owner;
+        x.state = 2; x.release = release; x.owner = owner; x.seq = ++c->seq;
     }
 }
 

@@ -66,6 +66,16 @@ constexpr bool kExperiments = true;
 constexpr bool kExperiments = false;
 #endif
 
+// Volume accesses of the brick kernels are ordinary (temporal) loads and stores, not the non-temporal ones of the row-shaped
+// kernels: a brick's row piece is 32 bytes (two lanes), the four x-neighbours a workgroup takes make up a 128-byte line between
+// them, and only with the line kept in L2 do their pieces leave as ONE memory request.  With the nt hint every piece went out
+// alone: PMC WRITE_SIZE 1 064 MB per 512^3 launch for 537 MB of weights.  Same box, nt -> temporal: the all-free-space launch
+// 0.0160 -> 0.0126 ms per frame, S-surf 512^3 0.0387 -> 0.0370, fr3 trajectory 1024^3 0.186 -> 0.178, S-surf 200^3 0.0077 -> 0.0072.
+#ifndef TSDF_BRICK_NT
+#define TSDF_BRICK_NT 0
+#endif
+constexpr bool kBrickNT = TSDF_BRICK_NT != 0;
+
 }  // namespace
 
 struct tsdf_volume {
@@ -82,7 +92,8 @@ struct tsdf_volume {
     tsdf_store::FrameStore *store;
     // the H2D copy of a frame runs on its own stream and overlaps the previous frame's kernel; the kernel waits for it
     hipStream_t copy_stream;
-    hipEvent_t flush_done;            // recorded on `stream` after every launch that read store slots: what they are released after
+    hipEvent_t flush_done[2];         // recorded on `stream` after every launch that read store slots: what they are released after;
+    int flush_parity;                 // two, used in turn, so that a slot of pass k is not held until pass k + 1 has run as well
     int table_slot;                   // the store's table slot of the launch being queued, or -1
     // Deferred integration of host frames (tsdf_integrate): the reference reads results back only in its destructor
     // (ref: src/tsdf.cu:101-104) and this library only at download / extraction / save, so the frames of successive
@@ -238,10 +249,14 @@ int store_slot(tsdf_volume *v, tsdf_store::SlotClass *c, hipStream_t first_user,
 // Everything queued on the handle's stream so far has read its store slots: they go back after flush_done.
 int store_release(tsdf_volume *v, tsdf_store::SlotClass *c, const int *idx, int n)
 {
-    HIP_TRY(hipEventRecord(v->flush_done, v->stream));
-    tsdf_store::slots_release_after(v->store, c, idx, n, &v->flush_done, v);
+    hipEvent_t *evt = &v->flush_done[v->flush_parity];
+    HIP_TRY(hipEventRecord(*evt, v->stream));
+    tsdf_store::slots_release_after(v->store, c, idx, n, evt, v);
     return TSDF_OK;
 }
+
+// the pass (a flush of collected frames, or one one-kernel-per-call frame) is queued: the next one records the other event
+void store_next_pass(tsdf_volume *v) { v->flush_parity ^= 1; }
 
 // The depth tile tables of the launch being queued (kMaxFramesPerLaunch tables): a table slot of the store, first written on the
 // handle's stream; tables_end() after the launch that reads them has been queued.
@@ -498,7 +513,7 @@ int launch_masked_bricks(tsdf_volume *v, tsdfk::IntegrateParams &p)
     hipLaunchKernelGGL(tsdfk::classify_bricks, dim3((unsigned)((n_bricks + 255) / 256)), dim3(256), 0, v->stream, p, pose,
                        v->d_wg_class, blocks, nz);
     p.wg_class = v->d_wg_class;
-    hipLaunchKernelGGL((tsdfk::integrate_single_bricks<true>), dim3(blocks, 1, nz), dim3(64, 4, 1), 0, v->stream, p, pose);
+    hipLaunchKernelGGL((tsdfk::integrate_single_bricks<kBrickNT>), dim3(blocks, 1, nz), dim3(64, 4, 1), 0, v->stream, p, pose);
     HIP_TRY(hipGetLastError());
     return tables_end(v);
 }
@@ -514,6 +529,7 @@ int launch_masked_bricks(tsdf_volume *v, tsdfk::IntegrateParams &p)
 //   8   as 0 but always classified
 //   1   the scalar kernel (any dim_x)
 // Every other number belongs to the measurement build (-DTSDF_EXPERIMENTS: tsdf_experiments.hip.h, `make experiments`).
+
 bool shipped_variant(int variant) { return variant == 0 || variant == 1 || variant == 3 || variant == 7 || variant == 8; }
 
 // Kernels that do not maintain the free-space summary must not leave stale "all ones" flags behind.
@@ -764,11 +780,11 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
         const unsigned char *wc = bl.counters;
         const tsdfk::ClassPoseTable *wp = bl.poses;
         if (label_ims)
-            hipLaunchKernelGGL((tsdfk::integrate_brick_list<true, true, false>), grid_list, block, 0, v->stream, mi, wl, wc, bl.bucket_cap, wp);
+            hipLaunchKernelGGL((tsdfk::integrate_brick_list<kBrickNT, true, false>), grid_list, block, 0, v->stream, mi, wl, wc, bl.bucket_cap, wp);
         else if (any_mask)
-            hipLaunchKernelGGL((tsdfk::integrate_brick_list<true, false, true>), grid_list, block, 0, v->stream, mi, wl, wc, bl.bucket_cap, wp);
+            hipLaunchKernelGGL((tsdfk::integrate_brick_list<kBrickNT, false, true>), grid_list, block, 0, v->stream, mi, wl, wc, bl.bucket_cap, wp);
         else
-            hipLaunchKernelGGL((tsdfk::integrate_brick_list<true, false, false>), grid_list, block, 0, v->stream, mi, wl, wc, bl.bucket_cap, wp);
+            hipLaunchKernelGGL((tsdfk::integrate_brick_list<kBrickNT, false, false>), grid_list, block, 0, v->stream, mi, wl, wc, bl.bucket_cap, wp);
         claims_total = (double)per_group * nz_groups * n;   // wavefront-frames = bricks x frames
         launched = true;
     }
@@ -860,6 +876,7 @@ int flush_pending(tsdf_volume *v)
         }
         if (rc == TSDF_OK) rc = store_release(v, &v->store->frames, v->pend_slot, n);
         if (rc == TSDF_OK && any_mask) rc = store_release(v, &v->store->masks, v->pend_mask_slot, n);
+        store_next_pass(v);
     }
     v->in_flush = false;
     if (e != hipSuccess) return fail(TSDF_ERR_HIP, "deferred integration: %s", hipGetErrorString(e));
@@ -948,7 +965,12 @@ int stream_waits_for_copies(tsdf_volume *v)
     return TSDF_OK;
 }
 
-int stage_end(tsdf_volume *v, const int *slots, int n) { return store_release(v, &v->store->frames, slots, n); }
+int stage_end(tsdf_volume *v, const int *slots, int n)
+{
+    const int rc = store_release(v, &v->store->frames, slots, n);
+    store_next_pass(v);
+    return rc;
+}
 
 int fill(tsdf_volume *v)
 {
@@ -1136,8 +1158,6 @@ int tsdf_create(const tsdf_config *cfg, tsdf_volume **out)
         return cleanup(fail(TSDF_ERR_HIP, "tsdf_create: hipStreamCreate: %s", hipGetErrorString(e)));
     v->stream = v->own_stream;
     v->defer_n = tsdfk::kMaxFramesPerLaunch;
-    if ((e = hipStreamCreateWithFlags(&v->copy_stream, hipStreamNonBlocking)) != hipSuccess)
-        return cleanup(fail(TSDF_ERR_HIP, "tsdf_create: hipStreamCreate: %s", hipGetErrorString(e)));
     size_t bytes = (size_t)(v->n_vox > 0 ? v->n_vox : 1) * sizeof(float);
     if ((e = hipMalloc((void **)&v->d_tsdf, bytes)) != hipSuccess ||
         (e = hipMalloc((void **)&v->d_weight, bytes)) != hipSuccess)
@@ -1155,10 +1175,12 @@ int tsdf_create(const tsdf_config *cfg, tsdf_volume **out)
         const int tw = (cfg->im_width + tsdfk::kTile - 1) / tsdfk::kTile, th = (cfg->im_height + tsdfk::kTile - 1) / tsdfk::kTile;
         const size_t table_bytes = (int64_t)tw * th <= 16384 ? tsdfk::kMaxFramesPerLaunch * tile_table_elems_host(tw, th) * sizeof(float2) : 0;
         if ((e = tsdf_store::store_ref(cfg->device, (size_t)cfg->im_height * cfg->im_width, table_bytes, &v->store)) != hipSuccess ||
-            (e = hipEventCreateWithFlags(&v->flush_done, hipEventDisableTiming)) != hipSuccess ||
+            (e = hipEventCreateWithFlags(&v->flush_done[0], hipEventDisableTiming)) != hipSuccess ||
+            (e = hipEventCreateWithFlags(&v->flush_done[1], hipEventDisableTiming)) != hipSuccess ||
             (e = hipEventCreateWithFlags(&v->pend_copied, hipEventDisableTiming)) != hipSuccess)
             return cleanup(fail(TSDF_ERR_HIP, "tsdf_create: frame store: %s", hipGetErrorString(e)));
         v->table_slot = -1;
+        v->copy_stream = v->store->copy_stream;   // the store's: shared by its handles (thread-safe; copies share one PCIe pipe anyway)
     }
     if ((rc = fill(v)) != TSDF_OK) return cleanup(rc);
     *out = v;
@@ -1179,7 +1201,7 @@ int tsdf_destroy(tsdf_volume *v)
         v->store = nullptr;
     }
     if (v->pend_copied) (void)hipEventDestroy(v->pend_copied);
-    if (v->flush_done) (void)hipEventDestroy(v->flush_done);
+    for (int i = 0; i < 2; ++i) if (v->flush_done[i]) (void)hipEventDestroy(v->flush_done[i]);
     for (int i = 0; i < kStageSlots; ++i) {
         if (v->h_frames[i]) (void)hipHostFree(v->h_frames[i]);
         if (v->d_frames[i]) (void)hipFree(v->d_frames[i]);
@@ -1206,7 +1228,6 @@ int tsdf_destroy(tsdf_volume *v)
     if (v->d_shortcut_stats) (void)hipFree(v->d_shortcut_stats);
     if (v->d_tsdf) (void)hipFree(v->d_tsdf);
     if (v->d_weight) (void)hipFree(v->d_weight);
-    if (v->copy_stream) (void)hipStreamDestroy(v->copy_stream);
     if (v->own_stream) (void)hipStreamDestroy(v->own_stream);
     delete v;
     return TSDF_OK;
@@ -2322,7 +2343,7 @@ int tsdf_batch_integrate_device(tsdf_batch *b, const float *depth_dev, const uin
         }
         hipLaunchKernelGGL(tsdfk::classify_bricks_batched, dim3((unsigned)((n_bricks + 255) / 256)), dim3(256), 0, b->stream,
                            b->d_params[s], b->d_poses[s], b->d_group_map, b->d_brick_class, brick_blocks, b->total_groups);
-        hipLaunchKernelGGL((tsdfk::integrate_multi_batched_bricks<true>), dim3(brick_blocks, 1, b->total_groups), block, 0, b->stream,
+        hipLaunchKernelGGL((tsdfk::integrate_multi_batched_bricks<kBrickNT>), dim3(brick_blocks, 1, b->total_groups), block, 0, b->stream,
                            b->d_params[s], b->d_poses[s], b->d_group_map, b->d_brick_class);
 #ifdef TSDF_EXPERIMENTS
     } else if (classify) {   // variant 11: a class per 1024-voxel workgroup patch (round 2a's shape)

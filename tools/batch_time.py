@@ -51,7 +51,7 @@ cover = float(np.mean([m.mean() / 255.0 for m in masks]))
 vox = n * E ** 3
 print(f"{n} volumes of {E}^3, masks: {args.masks} (mean coverage {cover:.2f} of the image)")
 NAMES = {0: "by policy (bricks)        ", 8: "forced on (bricks)        ", 11: "by policy (1024-voxel patches)", 7: "off                       ", 13: "round-2 brick workgroups   "}
-for cls, deferral in ((0, 32), (13, 32), (0, 0), (8, 0), (11, 0), (7, 0)):
+for cls, deferral in [(0, 32)] + ([(13, 32)] if capi.experiments_build() else []) + [(0, 0), (8, 0)] + ([(11, 0)] if capi.experiments_build() else []) + [(7, 0)]:
     with capi.Batch(cfgs) as batch:
         for v in batch.volumes:
             v.set_kernel_variant(cls)
