@@ -76,6 +76,7 @@ def parse():
                     "result/rgbd/associations.txt names them); when it exists the keyframes' real 16-bit depth frames are integrated "
                     "(value / 5000 m) instead of the rendered ones.  No dataset ships with the repository and none is fetched.")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--depth-cache", default="", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
     a = ap.parse_args()
     if not a.grid:
@@ -91,9 +92,14 @@ def parse():
 class Workload:
     """origin, truncation margin, base pose, the cam2world stream and the depth frame(s) it comes with."""
 
-    def __init__(self, name, dims, vs, noise_mm=0.0, holes=0.0, tum_dir=""):
+    def __init__(self, name, dims, vs, noise_mm=0.0, holes=0.0, tum_dir="", cache_dir=""):
         from semantic_slam_amd import synth
         self.name, self.dims, self.vs = name, dims, vs
+        # rendered frames are kept for the profiled child runs of this script (a rendering pass per child would cost more than
+        # the child): <cache_dir>/<workload>_<grid>_<voxel>_<noise>_<holes>.npy, float32 [frames, H, W]
+        cache = (os.path.join(cache_dir, f"tsdf_bench_{name}_{dims[0]}x{dims[1]}x{dims[2]}_{vs:g}_{noise_mm:g}_{holes:g}_{int(bool(tum_dir))}.npy")
+                 if cache_dir and name in ("ssurf", "traj") else "")
+        cached = np.load(cache, allow_pickle=False) if cache and os.path.isfile(cache) else None
         self.trunc = None            # None = the reference's 5 x voxel
         self.base2world = None
         self.full_coverage = False
@@ -111,7 +117,7 @@ class Workload:
             self.origin = synth.surf_volume(max(dims), vs, 1.0)
             scene = synth.SurfScene(dims, vs, self.origin)
             self.poses = np.stack([scene.pose(k, 64) for k in range(64)])
-            self.depths = [scene.depth(p, quantize=True) for p in self.poses]   # re-rendered per pose
+            self.depths = list(cached) if cached is not None else [scene.depth(p, quantize=True) for p in self.poses]   # re-rendered per pose
             self.desc = "sphere + wall seen from a 64-pose orbit, depth re-rendered per pose and quantised at 1/5000 m"
         else:   # traj: BASELINE configs[2]
             from semantic_slam_amd import ingest
@@ -126,7 +132,10 @@ class Workload:
             self.poses = np.stack([T.ravel() for T in Twc])
             # what the camera sees from each keyframe: rendered from the relative pose the library will compose
             names = [str(x) for x in np.load(gold, allow_pickle=False)["depth_names"]]
-            if tum_dir and all(os.path.isfile(os.path.join(tum_dir, nm)) for nm in names):
+            if cached is not None:
+                self.depths = list(cached)
+                self.desc = "(frames of the parent run)"
+            elif tum_dir and all(os.path.isfile(os.path.join(tum_dir, nm)) for nm in names):
                 # the sequence is there: the keyframes' own depth frames, raw 16-bit / 5000 (config/TUM3.yaml:34)
                 scale = np.float32(1.0) / np.float32(5000.0)
                 self.depths = [np.ascontiguousarray(ingest.load_depth_png(os.path.join(tum_dir, nm)).astype(np.float32) * scale) for nm in names]
@@ -137,11 +146,14 @@ class Workload:
                 self.desc = (f"the {len(self.poses)} keyframe poses of the reference's saved fr3_office run (result/rgbd/bundle.txt), "
                              "base = first keyframe, sphere + wall depth re-rendered per pose, quantised at 1/5000 m"
                              + ("" if not tum_dir else f" (--tum-dir {tum_dir} does not hold the named depth frames)"))
-        if name in ("ssurf", "traj") and (noise_mm > 0 or holes > 0):
+        if cached is None and name in ("ssurf", "traj") and (noise_mm > 0 or holes > 0):
             # a sensor's imperfections (Gaussian noise, sigma 2 mm; dropouts as zero blocks), then the
             # 1/5000 m quantisation again
             self.depths = synth.sensor_imperfections(self.depths, noise_mm, holes)
             self.desc += f"; Gaussian noise sigma {noise_mm:g} mm, {holes * 100:g} % of the image dropped in 8 x 8 blocks"
+        self.depths = [np.ascontiguousarray(d, np.float32) for d in self.depths]
+        if cache and cached is None:
+            np.save(cache, np.stack(self.depths))
         self.n_pose = len(self.poses)
 
     def block(self, start, n):
@@ -244,44 +256,92 @@ def cpu_baseline(args, W, cam_K, trunc):
 # ------------------------------------------------------------------------------------------------------------
 # roofline.traffic, measured by this run: two short rocprofv3 --pmc passes over a child run of this script
 # ------------------------------------------------------------------------------------------------------------
-def measure_traffic(args, kernel_substr, child_steps):
-    """HBM bytes per launch of the dominant kernel from the PMC counters, collected as MI355X_MICROARCH.md prescribes:
-    FETCH_SIZE and WRITE_SIZE in separate passes (they do not fit one), KiB units, FETCH_SIZE doubled on gfx950 for
-    wide coalesced reads, WRITE_SIZE exact.  Returns (bytes or None, note)."""
+def _pmc_pass(counters, kernel_substr, child_args, timeout=300):
+    """One `rocprofv3 --pmc <counters>` pass over a short child run of this script (`--pmc-child`: the launches only).
+    Returns ({counter: (median over the kernel's dispatches, dispatches)}, None) or (None, reason)."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
-    vals = {}
     tmp = os.environ.get("TMPDIR") or "/tmp"
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        d = tempfile.mkdtemp(prefix="bench_pmc_", dir=tmp)
-        cmd = [exe, "--pmc", counter, "-d", d, "-o", "p", "--output-format", "csv", "--",
-               sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--workload", args.workload,
-               "--grid", str(args.grid), "--mode", args.mode, "--variant", str(args.variant),
-               "--steps", str(child_steps), "--warmup", "2"]
-        try:
-            env = dict(os.environ, TMPDIR=tmp)
-            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
-                env.pop(k, None)
-            p = subprocess.run(cmd, cwd=tmp, env=env, timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
-            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-            if p.returncode != 0 or not files:
-                return None, f"rocprofv3 --pmc {counter} failed (rc {p.returncode}): {p.stderr.decode(errors='replace')[-200:]}"
-            v = [float(r["Counter_Value"]) for r in csv.DictReader(open(files[0]))
-                 if r["Counter_Name"] == counter and kernel_substr in r["Kernel_Name"]]
+    d = tempfile.mkdtemp(prefix="bench_pmc_", dir=tmp)
+    cmd = [exe, "--pmc"] + list(counters) + ["-d", d, "-o", "p", "--output-format", "csv", "--",
+                                             sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child"] + child_args
+    try:
+        env = dict(os.environ, TMPDIR=tmp)
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        p = subprocess.run(cmd, cwd=tmp, env=env, timeout=timeout, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if p.returncode != 0 or not files:
+            return None, f"rocprofv3 --pmc {' '.join(counters)} failed (rc {p.returncode}): {p.stderr.decode(errors='replace')[-200:]}"
+        out = {}
+        rows = [r for r in csv.DictReader(open(files[0])) if kernel_substr in r["Kernel_Name"]]
+        for c in counters:
+            v = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == c]
             if not v:
-                return None, f"no dispatch of {kernel_substr} in the {counter} pass"
-            vals[counter] = (float(np.median(v)), len(v))
-        except Exception as e:   # noqa: BLE001 -- the traffic figure is optional, the bench line is not
-            return None, f"rocprofv3 --pmc {counter}: {e!r}"[:300]
-        finally:
-            shutil.rmtree(d, ignore_errors=True)
+                return None, f"no dispatch of {kernel_substr} in the {c} pass"
+            v = v[len(v) // 3:]          # the first launches of a child run settle the per-launch decisions
+            out[c] = (float(np.median(v)), len(v))
+        return out, None
+    except Exception as e:   # noqa: BLE001 -- the counters are optional, the bench line is not
+        return None, f"rocprofv3 --pmc {' '.join(counters)}: {e!r}"[:300]
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def child_args_for(args, workload=None, mode=None, variant=None, grid=None, steps=64, noise_mm=None, holes=None):
+    a = ["--workload", workload or args.workload, "--grid", str(grid or args.grid), "--mode", mode or args.mode,
+         "--variant", str(args.variant if variant is None else variant), "--steps", str(steps), "--warmup", "2",
+         "--noise-mm", str(args.noise_mm if noise_mm is None else noise_mm), "--holes", str(args.holes if holes is None else holes)]
+    if args.tum_dir:
+        a += ["--tum-dir", args.tum_dir]
+    if args.depth_cache:
+        a += ["--depth-cache", args.depth_cache]
+    return a
+
+
+def measure_traffic(kernel_substr, child_args, wide_reads=True):
+    """HBM bytes per launch of the dominant kernel from the PMC counters, collected as MI355X_MICROARCH.md prescribes:
+    FETCH_SIZE and WRITE_SIZE in separate passes (they do not fit one), KiB units, FETCH_SIZE doubled on gfx950 (it tallies
+    the 128-byte requests of wide coalesced reads at 64 bytes), WRITE_SIZE as read.  Returns (bytes or None, note)."""
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        r, why = _pmc_pass([counter], kernel_substr, child_args)
+        if r is None:
+            return None, why
+        vals[counter] = r[counter]
     fetch, write = 2.0 * vals["FETCH_SIZE"][0] * 1024.0, vals["WRITE_SIZE"][0] * 1024.0
     note = (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes over a short child run of "
             f"the same workload), median over {vals['FETCH_SIZE'][1]} / {vals['WRITE_SIZE'][1]} dispatches of the kernel; KiB units, "
-            f"FETCH_SIZE x 2 (gfx950 counts wide coalesced reads at half their bytes), WRITE_SIZE exact: "
+            f"FETCH_SIZE x 2 (gfx950 counts wide coalesced reads at half their bytes), WRITE_SIZE as read: "
             f"read {fetch / 1e6:.1f} MB + written {write / 1e6:.1f} MB per launch")
+    if not wide_reads:
+        note += ("; this kernel reads the volume in 32-byte row pieces (ordinary loads, merged into whole lines in L2) and gathers "
+                 "4-byte depth samples -- the x 2 is calibrated on the all-free-space launch, whose bytes are known (DESIGN.md section 5)")
     return fetch + write, note
+
+
+VALU_CYCLES_PER_INST = 3.55    # issue cycles per VALU wave-instruction of the per-voxel kernel's mix (tools/microbench/valu_rate.hip prices
+                               # its 159 VALU instructions per wavefront-frame at 565 cycles: DESIGN.md section 4)
+
+
+def measure_valu(kernel_substr, child_args):
+    """What an issue-bound launch is measured against: VALU wave-instructions issued per SIMD, priced at the measured issue cost
+    of this kernel's instruction mix, over the launch's cycles (GRBM_GUI_ACTIVE summed over the 8 XCDs; 1024 SIMDs)."""
+    r, why = _pmc_pass(["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVES", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"], kernel_substr, child_args)
+    if r is None:
+        return None, why
+    cyc = r["GRBM_GUI_ACTIVE"][0] / 8.0
+    if cyc <= 0:
+        return None, "GRBM_GUI_ACTIVE read 0"
+    return {"valu_issue_frac": round(r["SQ_INSTS_VALU"][0] * VALU_CYCLES_PER_INST / (cyc * 1024.0), 4),
+            "valu_insts_per_launch": int(r["SQ_INSTS_VALU"][0]), "salu_insts_per_launch": int(r["SQ_INSTS_SALU"][0]),
+            "waves_per_launch": int(r["SQ_WAVES"][0]), "kernel_cycles": int(cyc),
+            "mean_waves_per_simd": round(r["SQ_WAVE_CYCLES"][0] * 4.0 / (cyc * 1024.0), 2),
+            "cycles_per_valu_inst_assumed": VALU_CYCLES_PER_INST,
+            "note": "one rocprofv3 --pmc pass over a short child run, median over "
+                    f"{r['SQ_INSTS_VALU'][1]} dispatches: valu_issue_frac = SQ_INSTS_VALU (wave instructions) x the measured issue cost of "
+                    "this instruction mix / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); 1.0 = the VALUs issue back to back"}, None
 
 
 def main():
@@ -314,7 +374,11 @@ def main():
     comm_dev = "cpu" if backend == "gloo" else "cuda"
 
     dims, vs, part_world = grid_for(args, world)
-    W = Workload(args.workload, dims, vs, args.noise_mm, args.holes, args.tum_dir)
+    cache_dir = args.depth_cache
+    own_cache = None
+    if not cache_dir and not args.no_traffic and not args.pmc_child and world == 1:
+        own_cache = cache_dir = tempfile.mkdtemp(prefix="bench_frames_", dir=os.environ.get("TMPDIR") or "/tmp")
+    W = Workload(args.workload, dims, vs, args.noise_mm, args.holes, args.tum_dir, cache_dir)
     D = args.grid
 
     # z-slab of this rank (ref layout is z-major, so a slab is one contiguous range)
@@ -344,6 +408,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    args.depth_cache = cache_dir      # what the child runs are told
     if args.pmc_child:   # profiled child of measure_traffic: the launches only
         run_block(vol, 0, args.warmup)
         run_block(vol, args.warmup, args.steps)
@@ -480,7 +545,10 @@ def main():
     traffic, traffic_note = None, "not measured (--no-traffic)"
     if not args.no_traffic and world == 1 and args.emulate_world <= 1:
         # the child launches what the timed region launched: single frames, or passes of the same number of frames
-        traffic, traffic_note = measure_traffic(args, ksub, 6 if fpl == 1 else 2 * int(round(K / (launches / repeats))))
+        if fpl > 1:
+            ksub = "integrate_brick_list<" if args.workload in ("ssurf", "traj", "sfull") and variant != 7 else "integrate_multi_inline<"
+        traffic, traffic_note = measure_traffic(ksub, child_args_for(args, variant=variant, steps=6 if fpl == 1 else 2 * int(round(K / (launches / repeats)))),
+                                                wide_reads="brick_list" not in ksub)
 
     mode_desc = ("one kernel launch per step (tsdf_integrate_device per frame: the reference's TSDF::Integrate call shape)" if fpl == 1
                  else f"tsdf_integrate_frames_device, up to {fpl} frames per pass over the volume")
@@ -556,6 +624,19 @@ def main():
                 "note": f"each voxel is read and written once per {ofpl} frames, so HBM is far from binding; the launch is bound by "
                         "VALU instruction issue (the exact projection, the reference's two divisions per update, eight compares per "
                         "voxel-frame: SQ counters and the per-instruction issue costs in profiles/ and DESIGN.md section 4)"}
+        if ofpl > 1 and not args.no_traffic:
+            # what the launch really moves and how busy its VALUs are: three short profiled child runs of the same leg
+            ca = child_args_for(args, mode="fused", variant=0, steps=4 * ofpl)
+            ksub_o = "integrate_brick_list<" if args.workload != "sband" else "integrate_multi_inline<"
+            tr, tr_note = measure_traffic(ksub_o, ca, wide_reads="brick_list" not in ksub_o)
+            vu, vu_note = measure_valu(ksub_o, ca)
+            r = rec.setdefault("roofline", {"bound": "valu_issue", "kernel_ms": round(ms_o * ofpl, 5)})
+            r["traffic"] = None if tr is None else int(tr)
+            r["traffic_note"] = tr_note
+            if tr is not None:
+                r["hbm_measured_GBps"] = round(tr / (ms_o * ofpl * 1e-3) / 1e9, 1)
+                r["hbm_measured_frac"] = round(tr / (ms_o * ofpl * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            r["valu"] = vu if vu is not None else {"error": vu_note}
         line["fused_sequence" if ofpl > 1 else "per_frame_launches"] = rec
         vol.set_kernel_variant(variant)
         vol.reset()
@@ -586,8 +667,8 @@ def main():
     if extras and args.workload in ("sband", "sfull"):
         # The realistic workload of SURVEY.md section 8(d): sphere + wall, orbit of 64 poses, depth re-rendered per pose
         # (64 frames resident in HBM), through the sequence path.
-        def realistic(noise_mm, holes, budget_ms):
-            Ws = Workload("ssurf", dims, vs, noise_mm, holes)
+        def realistic(noise_mm, holes, budget_ms, profile):
+            Ws = Workload("ssurf", dims, vs, noise_mm, holes, cache_dir=cache_dir)
             with capi.Volume(capi.make_config(dims, vs, Ws.origin, device=local_rank)) as sv_:
                 s_dev = [torch.from_numpy(d).cuda() for d in Ws.depths]
                 def sblock(start, n):
@@ -602,14 +683,59 @@ def main():
                 upd_r = float(w_r.astype(np.float64).sum()) / (192 + steps)
                 del w_r, s_dev
             ms_r = tot / steps
-            return {"workload": f"ssurf {dims[0]}x{dims[1]}x{dims[2]} @ {vs * 1000:g} mm: {Ws.desc}; fused sequence path",
-                    "ms_per_step": round(ms_r, 5), "value": round(n_global / ms_r / 1e3, 1), "unit": "Mvoxels/s",
-                    "updated_fraction": round(upd_r / n_global, 4), "frames": steps,
-                    "algorithmic_GBps_at_16B_per_update": round((16.0 * upd_r + frame_bytes) / (ms_r * 1e-3) / 1e9, 1)}
-        line["realistic_workload"] = realistic(0.0, 0.0, 150.0)
+            rec = {"workload": f"ssurf {dims[0]}x{dims[1]}x{dims[2]} @ {vs * 1000:g} mm: {Ws.desc}; fused sequence path",
+                   "ms_per_step": round(ms_r, 5), "value": round(n_global / ms_r / 1e3, 1), "unit": "Mvoxels/s",
+                   "updated_fraction": round(upd_r / n_global, 4), "frames": steps}
+            if profile and not args.no_traffic:
+                rec["roofline"] = leg_roofline("ssurf", dims[0], ms_r * 32, noise_mm, holes)
+            return rec
+
+        def leg_roofline(workload, grid, launch_ms, noise_mm=0.0, holes=0.0):
+            """Measured bytes and VALU share of a classified fused launch (integrate_brick_list): three short profiled child runs."""
+            ca = child_args_for(args, workload=workload, mode="fused", variant=0, grid=grid, steps=96, noise_mm=noise_mm, holes=holes)
+            tr, tr_note = measure_traffic("integrate_brick_list<", ca, wide_reads=False)
+            vu, vu_note = measure_valu("integrate_brick_list<", ca)
+            r = {"bound": "valu_issue", "launch_ms": round(launch_ms, 5), "frames_per_launch": 32,
+                 "traffic": None if tr is None else int(tr), "traffic_note": tr_note,
+                 "valu": vu if vu is not None else {"error": vu_note},
+                 "note": "launch_ms = HIP-event time per 32-frame launch (tile tables, brick work list and the Integrate kernel); traffic and "
+                         "the VALU share are the Integrate kernel's (integrate_brick_list, > 90 % of the launch)"}
+            if tr is not None:
+                r["hbm_measured_GBps"] = round(tr / (launch_ms * 1e-3) / 1e9, 1)
+                r["hbm_measured_frac"] = round(tr / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            return r
+
+        line["realistic_workload"] = realistic(0.0, 0.0, 150.0, True)
         # the same scene through a sensor's imperfections: Gaussian noise (sigma 2 mm, SURVEY.md 8d) and 5 % of every frame
         # dropped in 8 x 8 pixel blocks -- free-space bricks behind a dropout cannot be claimed as a whole any more
-        line["realistic_workload_noisy"] = realistic(2.0, 0.05, 60.0)
+        line["realistic_workload_noisy"] = realistic(2.0, 0.05, 60.0, False)
+        # BASELINE configs[2]: 1024^3 @ 2 mm on the 194 keyframe poses of the reference's saved fr3_office run, fused; 8.6 GB of
+        # volume + 238 MB of frames beside the headline's 1 GB -- only where the card has the room
+        free_b, _ = torch.cuda.mem_get_info()
+        if args.grid == 512 and free_b > 14 * 2 ** 30:
+            try:
+                d2, v2 = (1024, 1024, 1024), 0.002
+                Wt = Workload("traj", d2, v2, 0.0, 0.0, args.tum_dir, cache_dir)
+                with capi.Volume(capi.make_config(d2, v2, Wt.origin, base2world=Wt.base2world, device=local_rank)) as tv:
+                    t_dev = [torch.from_numpy(d).cuda() for d in Wt.depths]
+                    def tblock(start, n):
+                        poses, idx = Wt.block(start, n)
+                        return tv.integrate_frames_timed([t_dev[i].data_ptr() for i in idx], poses)
+                    tblock(0, Wt.n_pose)                      # one trip along the trajectory: buffers, decisions, clocks
+                    tot, steps = 0.0, 0
+                    while tot < 150.0:
+                        tot += tblock(steps, Wt.n_pose)
+                        steps += Wt.n_pose
+                    del t_dev
+                ms_t = tot / steps
+                n2 = d2[0] * d2[1] * d2[2]
+                rec = {"workload": f"traj 1024x1024x1024 @ 2 mm: {Wt.desc}; fused sequence path (BASELINE.json configs[2])",
+                       "ms_per_step": round(ms_t, 5), "value": round(n2 / ms_t / 1e3, 1), "unit": "Mvoxels/s", "frames": steps}
+                if not args.no_traffic:
+                    rec["roofline"] = leg_roofline("traj", 1024, ms_t * 32)
+                line["configs2_traj1024"] = rec
+            except Exception as e:   # noqa: BLE001 -- a companion leg must not take the line with it
+                line["configs2_traj1024"] = {"error": repr(e)[:300]}
     if extras and len(W.depths) == 1:
         # PCIe-inclusive rate of the reference-style call (tsdf_integrate: host depth pointer -> pinned staging -> H2D on a
         # copy stream).  By default the library collects such frames and applies them 32 at a time as one fused sequence
@@ -641,6 +767,8 @@ def main():
             line["cpu_reference"] = ref
     print(json.dumps(line))
     sys.stdout.flush()
+    if own_cache:
+        shutil.rmtree(own_cache, ignore_errors=True)
     if extraction_hung:
         os._exit(3)              # see above: the line is out, a collective is stuck on the other thread -> rc 3
     vol.close()
