@@ -146,3 +146,29 @@ def test_shape_validation():
         assert vol.brick_shape() == (q, r, s)
     with capi.Volume(capi.make_config((7, 8, 8), 0.01, [0, 0, 1])) as vol:      # scalar kernel: no brick view
         assert vol.brick_shape() == (0, 0, 0)
+
+
+def test_wide_flat_slices_fall_back_to_memory_order_on_the_per_voxel_path(cuda, oracle):
+    """The unclassified fused launch (variant 7) of a flat-mapped volume whose slice holds more than 65 535 workgroups: slices
+    fastest would put the workgroups of a slice into a slow grid dimension, so the launch must go out in memory order instead of
+    failing (or faulting) -- 8 200 x 8 200 voxels per slice = 65 664 workgroups.  Same bits as the oracle."""
+    dims, vs = (8200, 8200, 2), 0.0002
+    origin = np.array([-dims[0] * vs / 2, -dims[1] * vs / 2, 1.5], np.float32)
+    cfg = capi.make_config(dims, vs, origin)
+    assert dims[0] % 256 != 0 and (dims[0] * dims[1] // 256 + 3) // 4 > 65535
+    far = float(origin[2]) + dims[2] * vs
+    poses = [synth.identity_pose(), synth.make_pose(synth.rot_z(0.02), [0.003, -0.002, 0.0]), synth.make_pose(synth.rot_y(0.01), [0.0, 0.004, 0.0])]
+    depths = [np.full((480, 640), far + 0.2, np.float32) for _ in poses]
+    depths[1][:, 320:] = float(origin[2]) + 0.5 * dims[2] * vs          # a surface through the right half of the slab
+    depths[2][:240, :] = float(origin[2]) - 0.3                         # in front of the slab: nothing updated up there
+    ref_t, ref_w = oracle.init_grid(dims)
+    for p, d in zip(poses, depths):
+        oracle.integrate(cfg.cam_K, p, d, dims, origin, vs, cfg.trunc_margin, ref_t, ref_w, threads=16)
+    keep = [cuda.from_numpy(d).cuda() for d in depths]
+    for variant in (7, 8):
+        with capi.Volume(cfg) as vol:
+            vol.set_kernel_variant(variant)
+            vol.integrate_frames_device([d.data_ptr() for d in keep], np.stack(poses))
+            t, w = vol.download()
+        assert np.array_equal(w, ref_w) and np.array_equal(t.view(np.uint32), ref_t.view(np.uint32)), variant
+    assert ref_w.max() == 3 and ref_w.min() < 3
