@@ -460,6 +460,13 @@ def main():
             assert 0.0 < t_host.min() and t_host.max() < 1.0, "S-band: every TSDF value inside the truncation band"
     n_upd_per_frame = upd_total / frames_done
     del t_host, w_host
+    # several frames per pass over a scene with free / unseen space: what ONE launch touches (its voxels updated by at
+    # least one of its frames) is counted, not bounded -- a fresh volume, one launch's frames, weights > 0
+    touched_per_launch = None
+    if fpl > 1 and not W.full_coverage and world == 1:
+        vol.reset()
+        run_block(vol, frames_done, min(fpl, K))
+        touched_per_launch = float(np.count_nonzero(vol.download()[1]))
 
     # ---- after the timed region, N > 1: the one-voxel halo (RCCL) and the extraction it feeds --------------------
     extraction = None
@@ -532,10 +539,12 @@ def main():
         full, rem = divmod(K, fpl)
         launches = (full + (1 if rem else 0)) * repeats
         frames_per = K / (full + (1 if rem else 0))
-        units_per_launch = min(float(n_slab), frames_per * n_upd_per_frame)
+        units_per_launch = touched_per_launch if touched_per_launch is not None else min(float(n_slab), frames_per * n_upd_per_frame)
         alg_bytes = 16.0 * units_per_launch + frames_per * frame_bytes
-        unit_name = ("voxel touched by the launch (4 B TSDF + 4 B weight, read once and written once per launch; exact for "
-                     "full-coverage workloads, an upper bound otherwise)")
+        unit_name = ("voxel updated by at least one frame of the launch (4 B TSDF + 4 B weight, read once and written once per "
+                     "launch)" + ("" if touched_per_launch is None and W.full_coverage else
+                                  "; counted on a fresh volume after one launch's frames" if touched_per_launch is not None else
+                                  "; bounded by frames x updates per frame (N > 1: not counted)"))
         bytes_model = "16 B x voxels touched by the launch + frames per launch x (4*H*W + 100)"
     kernel_ms = kernel_ms_total / launches
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
@@ -544,14 +553,16 @@ def main():
                  "tsdfk::integrate_multi_single<true, true>") if variant in (0, 3) else f"variant {variant}"
         ksub = "integrate_tile<" if cfg.dim_x % 256 == 0 else "integrate_multi_single<"
     else:
-        kname = "tsdfk::integrate_multi_inline<1, true, FLAT, false, MASKS, C> (C = patch classification, decided per launch)"
-        ksub = "integrate_multi_inline<"
+        # what the library launches for a known sequence: over the brick work list while the previous launch's claims pay
+        # (decided per launch; the S-band and variant 7 never do), else per voxel
+        listed = args.workload in ("ssurf", "traj", "sfull") and variant != 7
+        kname = ("tsdfk::integrate_brick_list<false, false, false> over the work list of tsdfk::classify_brick_list (decided per launch)"
+                 if listed else "tsdfk::integrate_multi_inline<1, true, false, false, false> (every voxel projected)")
+        ksub = "integrate_brick_list<" if listed else "integrate_multi_inline<"
 
     traffic, traffic_note = None, "not measured (--no-traffic)"
     if not args.no_traffic and world == 1 and args.emulate_world <= 1:
         # the child launches what the timed region launched: single frames, or passes of the same number of frames
-        if fpl > 1:
-            ksub = "integrate_brick_list<" if args.workload in ("ssurf", "traj", "sfull") and variant != 7 else "integrate_multi_inline<"
         traffic, traffic_note = measure_traffic(ksub, child_args_for(args, variant=variant, steps=6 if fpl == 1 else 2 * int(round(K / (launches / repeats)))),
                                                 wide_reads="brick_list" not in ksub)
 

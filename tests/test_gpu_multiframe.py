@@ -199,9 +199,9 @@ def test_runs_of_free_space_frames_with_awkward_weights(cuda, oracle, variant):
 
 
 def test_wide_slices_fall_back_to_memory_order(cuda, oracle):
-    """A slice of 4096 x 2048 voxels has 65 536 brick workgroups -- one more than a slow grid dimension holds, so the
-    classified launch goes out in memory order (workgroups along x, slice groups along z) instead of slices fastest.
-    Same bits; claims are made."""
+    """A slice of 4096 x 2048 voxels holds 65 536 groups of four bricks -- one more than a slow grid dimension holds.  The
+    classified launch runs over the brick work list (a one-dimensional grid, so the limit no longer shapes it; the
+    measurement build's brick workgroups fall back to memory order here).  Same bits; claims are made."""
     dims, vs = (4096, 2048, 8), 0.00025
     origin = np.array([-dims[0] * vs / 2, -dims[1] * vs / 2, 1.2], np.float32)
     cfg = capi.make_config(dims, vs, origin)
