@@ -282,7 +282,9 @@ int tables_end(tsdf_volume *v)
 // (few depth tiles, a short range of camera depths) and how it coalesces (16q-byte row pieces).
 bool brick_shape_ok(const tsdf_config &c, int q, int r, int s)
 {
-    return c.dim_x % 4 == 0 && q >= 1 && r >= 1 && s >= 1 && q * r * s <= 64 && (c.dim_x / 4) % q == 0;
+    // (the last condition: a lane's byte offset within its brick is a 32-bit number in the kernels)
+    return c.dim_x % 4 == 0 && q >= 1 && r >= 1 && s >= 1 && q * r * s <= 64 && (c.dim_x / 4) % q == 0 &&
+           (long long)s * c.dim_x * c.dim_y < (1ll << 30);
 }
 
 // (host arithmetic only: also behind tsdf_default_brick_shape, which needs no device)
@@ -313,6 +315,7 @@ void choose_brick_for(const tsdf_config &c, int &bq, int &br, int &bs)
         if (quads % q) continue;
         for (int sl = 1; q * sl <= 64 && sl <= std::max(nz, 1); ++sl) {
             const int r = std::min(64 / (q * sl), std::max(c.dim_y, 1));
+            if (!brick_shape_ok(c, q, r, sl)) continue;
             const double X = 4.0 * q, Y = r, Z = sl;
             const double cost = (X + 8.0) * (Y + 8.0) * (Z + 10.0) / (X * Y * Z) * (1.0 + 0.25 / q) * 64.0 / (q * r * sl);
             if (cost < best) { best = cost; bq = q; br = r; bs = sl; }

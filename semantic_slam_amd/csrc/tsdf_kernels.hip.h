@@ -261,6 +261,7 @@ __device__ __forceinline__ int round_half_up_i32(float u)
 #define TSDF_FAST_D_MIN 8.6736174e-19f   /* 2^-60 */
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 
 template <bool NT>
 __device__ __forceinline__ float4 vol_load(const float *p)

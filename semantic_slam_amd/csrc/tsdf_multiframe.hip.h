@@ -524,6 +524,30 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
     static_assert(!BRICK || (R == 1 && !FLAT), "bricks are their own mapping");
     int xg, gy0;
     size_t row0, flag0;
+    // BRICK: the lane's quad as (wave-uniform start of the brick) + (32-bit byte offset of the lane within it).  With ordinary
+    // (temporal) accesses the two arrays are reached through buffer descriptors in scalar registers -- one offset register per
+    // lane instead of two 64-bit addresses held across the frame loop (the kernel sits at its 64-register budget: 5 spilled
+    // registers before, none of them now).  brick_shape_ok keeps a brick's span below 4 GiB.
+    size_t brick_base = 0;
+    unsigned int lane_byte = 0u;
+    constexpr bool kBuf = BRICK && !NT;
+    __amdgpu_buffer_rsrc_t t_buf, w_buf;
+    auto load_quad = [&](const bool tsdf, const int r) -> float4 {
+        if constexpr (kBuf) {
+            const v4u v = __builtin_amdgcn_raw_buffer_load_b128(tsdf ? t_buf : w_buf, (int)lane_byte, 0, 0);
+            return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        } else {
+            return vol_load<NT>((tsdf ? p.tsdf : p.weight) + row0 + (size_t)r * p.dim_x);
+        }
+    };
+    auto store_quad = [&](const bool tsdf, const int r, const float4 q) {
+        if constexpr (kBuf) {
+            const v4u v = {__float_as_uint(q.x), __float_as_uint(q.y), __float_as_uint(q.z), __float_as_uint(q.w)};
+            __builtin_amdgcn_raw_buffer_store_b128(v, tsdf ? t_buf : w_buf, (int)lane_byte, 0, 0);
+        } else {
+            vol_store<NT>((tsdf ? p.tsdf : p.weight) + row0 + (size_t)r * p.dim_x, q);
+        }
+    };
     int lzz = lz;            // the lane's slice of the slab (BRICK: lz counts groups of brick_s slices)
     // the summary word of the lane's quad: row segment (dim_x % 256 == 0) or 256-voxel chunk of the slice's linear view
     auto brick_flag_index = [&](const int gy, const int quad) -> size_t {
@@ -542,7 +566,13 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
         gy0 = g * p.brick_r + rr;
         lzz = lz * p.brick_s + zz;
         if (g >= p.brick_groups || zz >= p.brick_s || lzz >= p.nz || gy0 >= p.dim_y) return;
-        row0 = ((size_t)lzz * p.dim_y + gy0) * (size_t)p.dim_x + (size_t)xg * 4;
+        brick_base = ((size_t)(lz * p.brick_s) * p.dim_y + (size_t)(g * p.brick_r)) * (size_t)p.dim_x + (size_t)(i * p.brick_q) * 4;
+        lane_byte = (((unsigned)zz * (unsigned)p.dim_y + (unsigned)rr) * (unsigned)p.dim_x + (unsigned)qq * 4u) * 4u;
+        row0 = brick_base + (size_t)(lane_byte >> 2);
+        if constexpr (kBuf) {   // raw buffers (stride 0, byte offsets, no bound: the host guarantees the span), gfx950 descriptor word
+            t_buf = __builtin_amdgcn_make_buffer_rsrc(p.tsdf + brick_base, 0, -1, 0x00020000);
+            w_buf = __builtin_amdgcn_make_buffer_rsrc(p.weight + brick_base, 0, -1, 0x00020000);
+        }
         flag0 = brick_flag_index(gy0, xg);
     } else if constexpr (FLAT) {
         const int chunk = b0 * 4 + threadIdx.y;
@@ -596,8 +626,8 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             if (rowany[r] && !touched[r]) {
-                w4[r] = vol_load<NT>(p.weight + row0 + (size_t)r * p.dim_x);
-                if (!(fl[r] & 1u)) t4[r] = vol_load<NT>(p.tsdf + row0 + (size_t)r * p.dim_x);
+                w4[r] = load_quad(false, r);
+                if (!(fl[r] & 1u)) t4[r] = load_quad(true, r);
                 touched[r] = true;
             }
         }
@@ -894,8 +924,8 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
     for (int r = 0; r < R; ++r) {
         const bool store_t = __ballot(touched[r] && tchanged[r]) != 0ull;
         if (touched[r]) {
-            if (store_t) vol_store<NT>(p.tsdf + row0 + (size_t)r * p.dim_x, t4[r]);
-            vol_store<NT>(p.weight + row0 + (size_t)r * p.dim_x, w4[r]);
+            if (store_t) store_quad(true, r, t4[r]);
+            store_quad(false, r, w4[r]);
         }
         if ((fl[r] & 1u) && !ones[r]) {
             if constexpr (BRICK) {
