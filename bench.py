@@ -256,9 +256,10 @@ def cpu_baseline(args, W, cam_K, trunc):
 # ------------------------------------------------------------------------------------------------------------
 # roofline.traffic, measured by this run: two short rocprofv3 --pmc passes over a child run of this script
 # ------------------------------------------------------------------------------------------------------------
-def _pmc_pass(counters, kernel_substr, child_args, timeout=300):
+def _pmc_pass(counters, kernel_substr, child_args, keep, timeout=300):
     """One `rocprofv3 --pmc <counters>` pass over a short child run of this script (`--pmc-child`: the launches only).
-    Returns ({counter: (median over the kernel's dispatches, dispatches)}, None) or (None, reason)."""
+    Returns ({counter: (mean over the kernel's last `keep` dispatches -- the child's timed part; its warm-up launch may have
+    taken another kernel -- , dispatches)}, None) or (None, reason)."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
@@ -277,11 +278,11 @@ def _pmc_pass(counters, kernel_substr, child_args, timeout=300):
         out = {}
         rows = [r for r in csv.DictReader(open(files[0])) if kernel_substr in r["Kernel_Name"]]
         for c in counters:
-            v = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == c]
+            v = [float(r["Counter_Value"]) for r in sorted((r for r in rows if r["Counter_Name"] == c), key=lambda r: int(r["Dispatch_Id"]))]
+            v = v[-keep:]                # without the child's warm-up launches (they also settle the per-launch decisions)
             if not v:
                 return None, f"no dispatch of {kernel_substr} in the {c} pass"
-            v = v[len(v) // 3:]          # the first launches of a child run settle the per-launch decisions
-            out[c] = (float(np.median(v)), len(v))
+            out[c] = (float(np.mean(v)), len(v))
         return out, None
     except Exception as e:   # noqa: BLE001 -- the counters are optional, the bench line is not
         return None, f"rocprofv3 --pmc {' '.join(counters)}: {e!r}"[:300]
@@ -289,9 +290,12 @@ def _pmc_pass(counters, kernel_substr, child_args, timeout=300):
         shutil.rmtree(d, ignore_errors=True)
 
 
+CHILD_WARMUP = 2
+
+
 def child_args_for(args, workload=None, mode=None, variant=None, grid=None, steps=64, noise_mm=None, holes=None):
     a = ["--workload", workload or args.workload, "--grid", str(grid or args.grid), "--mode", mode or args.mode,
-         "--variant", str(args.variant if variant is None else variant), "--steps", str(steps), "--warmup", "2",
+         "--variant", str(args.variant if variant is None else variant), "--steps", str(steps), "--warmup", str(CHILD_WARMUP),
          "--noise-mm", str(args.noise_mm if noise_mm is None else noise_mm), "--holes", str(args.holes if holes is None else holes)]
     if args.tum_dir:
         a += ["--tum-dir", args.tum_dir]
@@ -300,23 +304,34 @@ def child_args_for(args, workload=None, mode=None, variant=None, grid=None, step
     return a
 
 
-def measure_traffic(kernel_substr, child_args, wide_reads=True):
+def _child_shape(child_args, fpl):
+    """(dispatches of the kernel in the timed part of a child run, frames they integrate)."""
+    steps = int(child_args[child_args.index("--steps") + 1])
+    return (steps + fpl - 1) // fpl, steps
+
+
+def measure_traffic(kernel_substr, child_args, fpl=1, wide_reads=True):
     """HBM bytes per launch of the dominant kernel from the PMC counters, collected as MI355X_MICROARCH.md prescribes:
     FETCH_SIZE and WRITE_SIZE in separate passes (they do not fit one), KiB units, FETCH_SIZE doubled on gfx950 (it tallies
-    the 128-byte requests of wide coalesced reads at 64 bytes), WRITE_SIZE as read.  Returns (bytes or None, note)."""
+    the 128-byte requests of wide coalesced reads at 64 bytes), WRITE_SIZE as read.  fpl > 1: the child integrates `--steps`
+    frames in passes of up to fpl, and the figure is the child's bytes per fpl frames (the launches of a trajectory differ
+    widely: the mean over the whole sequence is what the timed mean launch is to be compared with).  Returns (bytes or None, note)."""
+    keep, steps = _child_shape(child_args, fpl)
     vals = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        r, why = _pmc_pass([counter], kernel_substr, child_args)
+        r, why = _pmc_pass([counter], kernel_substr, child_args, keep)
         if r is None:
             return None, why
         vals[counter] = r[counter]
-    fetch, write = 2.0 * vals["FETCH_SIZE"][0] * 1024.0, vals["WRITE_SIZE"][0] * 1024.0
+    scale = 1.0 if fpl == 1 else vals["FETCH_SIZE"][1] * fpl / float(steps)      # dispatches -> launches of fpl frames
+    fetch, write = 2.0 * vals["FETCH_SIZE"][0] * 1024.0 * scale, vals["WRITE_SIZE"][0] * 1024.0 * scale
     note = (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes over a short child run of "
-            f"the same workload), median over {vals['FETCH_SIZE'][1]} / {vals['WRITE_SIZE'][1]} dispatches of the kernel; KiB units, "
+            f"the same workload), mean over {vals['FETCH_SIZE'][1]} / {vals['WRITE_SIZE'][1]} dispatches of the kernel"
+            + (f" ({steps} consecutive frames, scaled to {fpl} frames)" if fpl > 1 else "") + "; KiB units, "
             f"FETCH_SIZE x 2 (gfx950 counts wide coalesced reads at half their bytes), WRITE_SIZE as read: "
             f"read {fetch / 1e6:.1f} MB + written {write / 1e6:.1f} MB per launch")
     if not wide_reads:
-        note += ("; this kernel reads the volume in 32-byte row pieces (ordinary loads, merged into whole lines in L2) and gathers "
+        note += ("; this kernel reads the volume in 32-byte row pieces (buffer loads, merged into whole lines in L2) and gathers "
                  "4-byte depth samples -- the x 2 is calibrated on the all-free-space launch, whose bytes are known (DESIGN.md section 5)")
     return fetch + write, note
 
@@ -325,22 +340,26 @@ VALU_CYCLES_PER_INST = 3.55    # issue cycles per VALU wave-instruction of the p
                                # its 159 VALU instructions per wavefront-frame at 565 cycles: DESIGN.md section 4)
 
 
-def measure_valu(kernel_substr, child_args):
+def measure_valu(kernel_substr, child_args, fpl=32):
     """What an issue-bound launch is measured against: VALU wave-instructions issued per SIMD, priced at the measured issue cost
     of this kernel's instruction mix, over the launch's cycles (GRBM_GUI_ACTIVE summed over the 8 XCDs; 1024 SIMDs)."""
-    r, why = _pmc_pass(["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVES", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"], kernel_substr, child_args)
+    r, why = _pmc_pass(["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVES", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"], kernel_substr, child_args,
+                       _child_shape(child_args, fpl)[0])
     if r is None:
         return None, why
     cyc = r["GRBM_GUI_ACTIVE"][0] / 8.0
     if cyc <= 0:
         return None, "GRBM_GUI_ACTIVE read 0"
+    steps = _child_shape(child_args, fpl)[1]
+    per = r["SQ_INSTS_VALU"][1] * fpl / float(steps) if fpl > 1 else 1.0      # dispatches -> launches of fpl frames
     return {"valu_issue_frac": round(r["SQ_INSTS_VALU"][0] * VALU_CYCLES_PER_INST / (cyc * 1024.0), 4),
-            "valu_insts_per_launch": int(r["SQ_INSTS_VALU"][0]), "salu_insts_per_launch": int(r["SQ_INSTS_SALU"][0]),
-            "waves_per_launch": int(r["SQ_WAVES"][0]), "kernel_cycles": int(cyc),
+            "valu_insts_per_launch": int(r["SQ_INSTS_VALU"][0] * per), "salu_insts_per_launch": int(r["SQ_INSTS_SALU"][0] * per),
+            "waves_per_launch": int(r["SQ_WAVES"][0] * per), "kernel_cycles": int(cyc * per),
             "mean_waves_per_simd": round(r["SQ_WAVE_CYCLES"][0] * 4.0 / (cyc * 1024.0), 2),
             "cycles_per_valu_inst_assumed": VALU_CYCLES_PER_INST,
-            "note": "one rocprofv3 --pmc pass over a short child run, median over "
-                    f"{r['SQ_INSTS_VALU'][1]} dispatches: valu_issue_frac = SQ_INSTS_VALU (wave instructions) x the measured issue cost of "
+            "note": "one rocprofv3 --pmc pass over a short child run, means over "
+                    f"{r['SQ_INSTS_VALU'][1]} dispatches ({steps} consecutive frames; per-launch figures scaled to {fpl} frames): "
+                    "valu_issue_frac = SQ_INSTS_VALU (wave instructions) x the measured issue cost of "
                     "this instruction mix / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); 1.0 = the VALUs issue back to back"}, None
 
 
@@ -410,8 +429,8 @@ def main():
 
     args.depth_cache = cache_dir      # what the child runs are told
     if args.pmc_child:   # profiled child of measure_traffic: the launches only
-        run_block(vol, 0, args.warmup)
-        run_block(vol, args.warmup, args.steps)
+        run_block(vol, W.n_pose - args.warmup % W.n_pose, args.warmup)     # warm-up on the sequence's last poses ...
+        run_block(vol, 0, args.steps)                                      # ... then the sequence from its start, as the timed legs run it
         vol.close()
         return
 
@@ -460,13 +479,23 @@ def main():
             assert 0.0 < t_host.min() and t_host.max() < 1.0, "S-band: every TSDF value inside the truncation band"
     n_upd_per_frame = upd_total / frames_done
     del t_host, w_host
-    # several frames per pass over a scene with free / unseen space: what ONE launch touches (its voxels updated by at
-    # least one of its frames) is counted, not bounded -- a fresh volume, one launch's frames, weights > 0
+    # several frames per pass over a scene with free / unseen space: what a launch touches (its voxels updated by at least one
+    # of its frames) is counted, not bounded -- every launch of one pass over the step sequence on a fresh volume, weights > 0
+    # counted on the device; per fpl frames, like the measured traffic it is compared with
     touched_per_launch = None
     if fpl > 1 and not W.full_coverage and world == 1:
-        vol.reset()
-        run_block(vol, frames_done, min(fpl, K))
-        touched_per_launch = float(np.count_nonzero(vol.download()[1]))
+        nz_s = ze - zb
+        t_dev = torch.empty(n_slab, dtype=torch.float32, device="cuda")
+        w_dev = torch.empty(n_slab, dtype=torch.float32, device="cuda")
+        seq = W.n_pose if W.n_pose >= 2 * fpl else 3 * fpl        # the frames the traffic children run
+        total = 0
+        for start in range(0, seq, fpl):
+            vol.reset()
+            run_block(vol, start, min(fpl, seq - start))
+            vol.copy_slices_to_device(0, nz_s, t_dev.data_ptr(), w_dev.data_ptr())
+            total += int(torch.count_nonzero(w_dev))
+        touched_per_launch = total * fpl / float(seq)
+        del t_dev, w_dev
 
     # ---- after the timed region, N > 1: the one-voxel halo (RCCL) and the extraction it feeds --------------------
     extraction = None
@@ -543,7 +572,7 @@ def main():
         alg_bytes = 16.0 * units_per_launch + frames_per * frame_bytes
         unit_name = ("voxel updated by at least one frame of the launch (4 B TSDF + 4 B weight, read once and written once per "
                      "launch)" + ("" if touched_per_launch is None and W.full_coverage else
-                                  "; counted on a fresh volume after one launch's frames" if touched_per_launch is not None else
+                                  "; counted per launch on a fresh volume over one pass of the pose sequence, mean per 32 frames" if touched_per_launch is not None else
                                   "; bounded by frames x updates per frame (N > 1: not counted)"))
         bytes_model = "16 B x voxels touched by the launch + frames per launch x (4*H*W + 100)"
     kernel_ms = kernel_ms_total / launches
@@ -563,8 +592,8 @@ def main():
     traffic, traffic_note = None, "not measured (--no-traffic)"
     if not args.no_traffic and world == 1 and args.emulate_world <= 1:
         # the child launches what the timed region launched: single frames, or passes of the same number of frames
-        traffic, traffic_note = measure_traffic(ksub, child_args_for(args, variant=variant, steps=6 if fpl == 1 else 2 * int(round(K / (launches / repeats)))),
-                                                wide_reads="brick_list" not in ksub)
+        traffic, traffic_note = measure_traffic(ksub, child_args_for(args, variant=variant, steps=6 if fpl == 1 else W.n_pose if W.n_pose >= 2 * fpl else 3 * fpl),
+                                                fpl=fpl, wide_reads="brick_list" not in ksub)
 
     mode_desc = ("one kernel launch per step (tsdf_integrate_device per frame: the reference's TSDF::Integrate call shape)" if fpl == 1
                  else f"tsdf_integrate_frames_device, up to {fpl} frames per pass over the volume")
@@ -644,8 +673,8 @@ def main():
             # what the launch really moves and how busy its VALUs are: three short profiled child runs of the same leg
             ca = child_args_for(args, mode="fused", variant=0, steps=4 * ofpl)
             ksub_o = "integrate_brick_list<" if args.workload != "sband" else "integrate_multi_inline<"
-            tr, tr_note = measure_traffic(ksub_o, ca, wide_reads="brick_list" not in ksub_o)
-            vu, vu_note = measure_valu(ksub_o, ca)
+            tr, tr_note = measure_traffic(ksub_o, ca, fpl=ofpl, wide_reads="brick_list" not in ksub_o)
+            vu, vu_note = measure_valu(ksub_o, ca, ofpl)
             r = rec.setdefault("roofline", {"bound": "valu_issue", "kernel_ms": round(ms_o * ofpl, 5)})
             r["traffic"] = None if tr is None else int(tr)
             r["traffic_note"] = tr_note
@@ -708,9 +737,11 @@ def main():
 
         def leg_roofline(workload, grid, launch_ms, noise_mm=0.0, holes=0.0):
             """Measured bytes and VALU share of a classified fused launch (integrate_brick_list): three short profiled child runs."""
-            ca = child_args_for(args, workload=workload, mode="fused", variant=0, grid=grid, steps=96, noise_mm=noise_mm, holes=holes)
-            tr, tr_note = measure_traffic("integrate_brick_list<", ca, wide_reads=False)
-            vu, vu_note = measure_valu("integrate_brick_list<", ca)
+            # the children run whole passes over the pose sequence (the trajectory's launches differ widely)
+            ca = child_args_for(args, workload=workload, mode="fused", variant=0, grid=grid, steps=194 if workload == "traj" else 128,
+                                noise_mm=noise_mm, holes=holes)
+            tr, tr_note = measure_traffic("integrate_brick_list<", ca, fpl=32, wide_reads=False)
+            vu, vu_note = measure_valu("integrate_brick_list<", ca, 32)
             r = {"bound": "valu_issue", "launch_ms": round(launch_ms, 5), "frames_per_launch": 32,
                  "traffic": None if tr is None else int(tr), "traffic_note": tr_note,
                  "valu": vu if vu is not None else {"error": vu_note},
