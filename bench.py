@@ -61,6 +61,13 @@ def parse():
                     help="N > 1: weak = every rank integrates a slab as large as the whole N = 1 grid (the global grid "
                          "grows with N: 512^3 -> 512x512x1024 -> 512x1024x1024 -> 1024^3 at N = 1, 2, 4, 8, same physical "
                          "extent, finer voxels); strong = the N = 1 grid cut into N slabs")
+    ap.add_argument("--dist-world1", action="store_true",
+                    help="with one rank: still create the process group and run the N > 1 code path (barriers, all-reduces, halo step, "
+                         "multi_gpu object) -- the RCCL rehearsal a one-GPU box allows (tests/test_gpu_bench_cli.py)")
+    ap.add_argument("--extract-deadline", type=float, default=120.0, help="seconds the post-run halo + extraction step may take")
+    ap.add_argument("--inject-fault", choices=["none", "raise", "hang"], default="none",
+                    help="tests only: make the halo + extraction step fail / never return (the line must still be printed and the "
+                         "exit code must say so: 4 / 3)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="single-GPU rehearsal of one rank of an N-GPU job: integrate only rank 0's z-slab of N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -383,9 +390,16 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    multi = world > 1 or args.dist_world1
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1 and "RANK" not in os.environ:      # --dist-world1 without a launcher
+            import socket
+            so = socket.socket()
+            so.bind(("127.0.0.1", 0))
+            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK=str(local_rank), MASTER_PORT=str(so.getsockname()[1]))
+            so.close()
         if backend == "gloo":
             dist.init_process_group("gloo")
         else:
@@ -500,10 +514,14 @@ def main():
     # ---- after the timed region, N > 1: the one-voxel halo (RCCL) and the extraction it feeds --------------------
     extraction = None
     extraction_hung = False
-    if world > 1 and not args.no_extract:
+    if multi and not args.no_extract:
         def halo_and_extract():
             try:
                 torch.cuda.set_device(local_rank)      # the current device is per thread
+                if args.inject_fault == "raise":
+                    raise RuntimeError("injected fault (--inject-fault raise)")
+                if args.inject_fault == "hang":
+                    threading.Event().wait()
                 from semantic_slam_amd.sharded import ShardedVolume
                 sv = ShardedVolume(dims, lambda a, b: vol, dist=dist, comm_device=comm_dev)
                 assert (sv.z_begin, sv.z_end) == (zb, ze)
@@ -531,10 +549,10 @@ def main():
         box = {}
         th = threading.Thread(target=lambda: box.update(r=halo_and_extract()), daemon=True)
         th.start()
-        th.join(120.0)
+        th.join(args.extract_deadline)
         if th.is_alive():
             extraction_hung = True
-            extraction = {"error": "halo exchange + extraction did not finish within 120 s; the line is printed without it"}
+            extraction = {"error": f"halo exchange + extraction did not finish within {args.extract_deadline:g} s; the line is printed without it"}
         else:
             extraction = box.get("r")
 
@@ -630,7 +648,7 @@ def main():
                      "note": "per-rank slab launch; kernel_ms = HIP-event time of the timed region (events on the handle's "
                              "stream) / launches; achieved = algorithmic_bytes_per_launch / kernel_ms"},
     }
-    if world > 1:
+    if multi:
         # what a SCALE record must show: how many ranks the communicator saw, through which backend, and what the halo costs
         line["multi_gpu"] = {"world": world, "backend": "rccl (torch.distributed 'nccl')" if backend != "gloo" else "gloo",
                              "comm_device": comm_dev, "halo_bytes_per_boundary": 8 * dims[0] * dims[1],

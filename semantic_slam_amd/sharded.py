@@ -37,6 +37,24 @@ def slab_range(dim_z, rank, world):
     return rank * dim_z // world, (rank + 1) * dim_z // world
 
 
+def exchange_slices(dist, group, send, lower, recv, upper):
+    """The wire of the one-voxel halo: buffer `send` (or None) to global rank `lower` and buffer `recv` (or None) from
+    global rank `upper`, as ONE grouped point-to-point call (RCCL for device buffers, gloo for host buffers).  Returns
+    when `recv` may be read by any stream (the extraction kernels run on the slab's own stream, not on torch's)."""
+    ops = []
+    if send is not None:
+        ops.append(dist.P2POp(dist.isend, send, lower, group))
+    if recv is not None:
+        ops.append(dist.P2POp(dist.irecv, recv, upper, group))
+    if not ops:
+        return
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+    if (recv is not None and recv.is_cuda) or (send is not None and send.is_cuda):
+        import torch
+        torch.cuda.current_stream().synchronize()
+
+
 class ShardedVolume:
     def __init__(self, dims, make_slab, dist=None, group=None, comm_device="cpu"):
         """dims: global (dim_x, dim_y, dim_z).  make_slab(z_begin, z_end) -> slab object for this
@@ -108,21 +126,17 @@ class ShardedVolume:
         upper = owners[i + 1] if i + 1 < len(owners) else None
         n = self.slice_voxels
         dev = self._torch_dev()
-        ops, recv = [], None
+        send = recv = None
         if lower is not None:
             send = torch.empty(2 * n, dtype=torch.float32, device=dev)
             self._slices_into(send, 0, 1)
-            ops.append(dist.P2POp(dist.isend, send, self._global_rank(lower), self.group))
         if upper is not None:
             recv = torch.empty(2 * n, dtype=torch.float32, device=dev)
-            ops.append(dist.P2POp(dist.irecv, recv, self._global_rank(upper), self.group))
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
+        exchange_slices(dist, self.group, send, None if lower is None else self._global_rank(lower),
+                        recv, None if upper is None else self._global_rank(upper))
         if recv is None:
             return None
         if recv.is_cuda:
-            torch.cuda.current_stream().synchronize()   # the extraction runs on the slab's own stream
             self._halo_buf = recv
             return recv.data_ptr(), recv.data_ptr() + 4 * n
         host = recv.numpy()

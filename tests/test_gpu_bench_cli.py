@@ -1,0 +1,84 @@
+"""bench.py as the driver runs it: the one-line contract, the N-rank launch, and what a dead wire does to the exit code.
+
+  * N = 1: one JSON line with the contract's keys, `roofline` (frac <= 1, kernel time <= step time) and `config.workload`.
+  * N = 2 over gloo (two ranks share the box's one card; RCCL refuses that): `python -m torch.distributed.run` as the
+    driver launches it, one line from rank 0, rc 0, `multi_gpu.world` = 2, halo + extraction ran.
+  * one rank over RCCL (`--dist-world1`): the same code path -- process group on RCCL, barriers, all-reduces on device
+    tensors, the halo step (no neighbour), extraction, `multi_gpu` -- on the real library.
+  * a halo step that raises / never returns: the line is still printed, the process exits 4 / 3.
+Short runs (--steps 5, no companion legs, no PMC passes, no CPU baseline)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+QUICK = ["--steps", "5", "--warmup", "2", "--no-extras", "--no-traffic", "--no-cpu-baseline"]
+
+
+def run(cmd, env=None, timeout=300):
+    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    p = subprocess.run(cmd, cwd=ROOT, env=e, timeout=timeout, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    return p.returncode, lines, p.stderr.decode()[-2000:]
+
+
+def test_one_gpu_line_keeps_the_contract(cuda):
+    rc, lines, err = run([sys.executable, "bench.py"] + QUICK)
+    assert rc == 0, err
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["unit"] == "Mvoxels/s" and d["dtype"] == "f32"
+    assert d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "512x512x512" in d["config"]["workload"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert 0.3 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["kernel_ms"] <= d["ms_per_step"] * 1.001
+    assert r["algorithmic_bytes_per_unit"] == 16 and r["units_per_launch"] == 512 ** 3
+    # value = voxels x steps / time
+    assert abs(d["value"] - 512 ** 3 / d["ms_per_step"] / 1e3) / d["value"] < 2e-3
+
+
+def test_two_ranks_as_the_driver_launches_them(cuda):
+    rc, lines, err = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29571", "bench.py", "--gpus", "2", "--grid", "256"] + QUICK, env={"TSDF_BENCH_BACKEND": "gloo"})
+    assert rc == 0, err
+    assert len(lines) == 1, "rank 0 alone prints"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    m = d["multi_gpu"]
+    assert m["world"] == 2 and m["backend"] == "gloo" and m["data_path_collectives"] == 0 and m["halo_and_extraction_ran"] is True
+    assert m["halo_bytes_per_boundary"] == 8 * d["config"]["grid"][0] * d["config"]["grid"][1]
+    assert d["extraction_hung"] is False and d["extraction"]["vertices"] >= 0 and "error" not in d["extraction"]
+    # weak scaling: the grid doubled along z, every rank owns what N = 1 owns
+    assert d["config"]["grid"] == [256, 256, 512] and "2 z-slab(s) of 256 slices" in d["config"]["partition"]
+
+
+def test_one_rank_runs_the_multi_gpu_path_over_rccl(cuda):
+    rc, lines, err = run([sys.executable, "bench.py", "--dist-world1", "--grid", "256"] + QUICK)
+    assert rc == 0, err
+    d = json.loads(lines[0])
+    m = d["multi_gpu"]
+    assert m["world"] == 1 and m["backend"].startswith("rccl") and m["comm_device"] == "cuda" and m["halo_and_extraction_ran"] is True
+    assert d["extraction"]["backend"].startswith("rccl") and d["extraction_hung"] is False
+
+
+@pytest.mark.parametrize("fault,code", [("raise", 4), ("hang", 3)])
+def test_a_dead_wire_shows_in_the_exit_code(cuda, fault, code):
+    rc, lines, err = run([sys.executable, "bench.py", "--dist-world1", "--grid", "256", "--inject-fault", fault, "--extract-deadline", "3"] + QUICK)
+    assert rc == code, (rc, err)
+    assert len(lines) == 1, "the line is printed all the same"
+    d = json.loads(lines[0])
+    assert "error" in d["extraction"] and d["extraction_hung"] is (fault == "hang")
+    assert d["multi_gpu"]["halo_and_extraction_ran"] is False
+    assert d["value"] > 0
