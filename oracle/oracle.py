@@ -255,6 +255,46 @@ class Ref:
         return int(self.lib.ref_max_threads())
 
 
+class RefHost:
+    """The reference's own host functions that compile as they stand: multiply_matrix / invert_matrix (src/tsdf.cu:253-403)
+    and the .ply writer SaveVoxelGrid2SurfacePointCloud (src/tsdf.cu:170-218).  oracle/Makefile, ref_host;
+    oracle/ref_host_driver.cpp says what is and is not the reference's in that build."""
+
+    path = os.path.join(_HERE, "_ref", "libtsdf_ref_host.so")
+
+    @classmethod
+    def available(cls):
+        return os.path.isfile(cls.path)
+
+    def __init__(self):
+        L = self.lib = C.CDLL(self.path)
+        L.ref_multiply_matrix.argtypes = [_f32p, _f32p, _f32p]
+        L.ref_multiply_matrix.restype = None
+        L.ref_invert_matrix.argtypes = [_f32p, _f32p]
+        L.ref_invert_matrix.restype = C.c_int
+        L.ref_save_ply.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
+                                   _f32p, _f32p, C.c_float, C.c_float]
+        L.ref_save_ply.restype = None
+
+    def multiply(self, a, b):
+        out = np.empty(16, np.float32)
+        self.lib.ref_multiply_matrix(_f32(a).ravel(), _f32(b).ravel(), out)
+        return out
+
+    def invert(self, m):
+        """(ok, inverse); as in the reference the output is left untouched when det == 0 (returned as NaNs here)."""
+        out = np.full(16, np.nan, np.float32)
+        ok = self.lib.ref_invert_matrix(_f32(m).ravel(), out)
+        return bool(ok), out
+
+    def save_ply(self, path, tsdf, weight, dims, voxel_size, origin, tsdf_thresh=1.2, weight_thresh=0.9):
+        """tsdf<id>.ply as ~TSDF writes it (ref: src/tsdf.cu:110-112 passes 1.2f, 0.9f)."""
+        dx, dy, dz = (int(d) for d in dims)
+        t, w = _f32(tsdf).ravel(), _f32(weight).ravel()
+        assert t.size == dx * dy * dz == w.size
+        self.lib.ref_save_ply(os.fsencode(path), dx, dy, dz, voxel_size, origin[0], origin[1], origin[2], t, w, tsdf_thresh, weight_thresh)
+
+
 class RefHip:
     """The reference's own GpuIntegrate compiled for gfx950 by hipcc exactly as it stands
     (`make -C oracle ref_hip`: no stand-in for anything) and launched with the reference's shape

@@ -68,6 +68,12 @@ def test_object_callsite_sequence(cuda, oracle, tmp_path):
     oracle.save_bin(str(tmp_path / "want.bin"), ref_t, dims, origin, vs, trunc)
     assert (tmp_path / f"tsdf{vol_id}.bin").read_bytes() == (tmp_path / "want.bin").read_bytes()
     assert (tmp_path / f"tsdf{vol_id}.ply").read_bytes() == (tmp_path / "want.ply").read_bytes()
+    # ... and the reference's own writer (src/tsdf.cu:170-218 compiled as it stands, oracle/ref_host_driver.cpp), called as
+    # ~TSDF calls it, on the product's downloaded volume: the file the drop-in's destructor wrote, byte for byte
+    from oracle.oracle import RefHost
+    if RefHost.available():
+        RefHost().save_ply(str(tmp_path / "ref.ply"), ref_t, ref_w, dims, vs, origin)
+        assert (tmp_path / f"tsdf{vol_id}.ply").read_bytes() == (tmp_path / "ref.ply").read_bytes()
 
 
 def test_destructor_reports_a_failed_file_and_never_throws(cuda, tmp_path):

@@ -324,6 +324,10 @@ def test_surface_and_files_match_oracle(cuda, oracle, tmp_path):
     oracle.save_bin(str(tmp_path / "b.bin"), ref_t, dims, origin, vs, cfg.trunc_margin)
     assert (tmp_path / "a.ply").read_bytes() == (tmp_path / "b.ply").read_bytes()
     assert (tmp_path / "a.bin").read_bytes() == (tmp_path / "b.bin").read_bytes()
+    from oracle.oracle import RefHost      # the reference's own .ply writer, compiled as it stands (oracle/ref_host_driver.cpp)
+    if RefHost.available():
+        RefHost().save_ply(str(tmp_path / "r.ply"), ref_t, ref_w, dims, vs, origin)
+        assert (tmp_path / "a.ply").read_bytes() == (tmp_path / "r.ply").read_bytes()
 
 
 @pytest.mark.parametrize("path", ["frame", "fused", "fused_classified", "fused_per_voxel"])

@@ -1,10 +1,12 @@
 """4x4 helpers (ref: src/tsdf.cu:253-273 multiply_matrix, :276-403 invert_matrix).
 
-These are member functions of a class whose header needs OpenCV + CUDA, so the reference's own
-code cannot be built for them: PARITY UNPINNED by reference output.  They are checked by
-known-answer tests, by an independent numpy-float32 emulation of the same operation order, and
-the product's host implementation (csrc/pose_math.h, exported by libtsdf_hip.so) is checked
-bit-for-bit against the oracle's independently written one.
+They are members of a class whose header needs OpenCV + CUDA, so the class cannot be built here.  Their two definitions are
+plain arithmetic, though, and `make -C oracle ref_host` compiles them as they stand (behind two prototypes at namespace
+scope, oracle/ref_host_driver.cpp) into oracle/_ref/libtsdf_ref_host.so: the tests at the bottom of this file hold the
+oracle's and the product's implementations, and the pose composition of TSDF::TSDF / TSDF::Integrate (src/tsdf.cu:74,142), to
+that build bit for bit.  Above them: known-answer tests, an independent numpy-float32 emulation of the same operation
+order, and the product's host implementation (csrc/pose_math.h, exported by libtsdf_hip.so) against the oracle's
+independently written one.
 """
 import numpy as np
 import pytest
@@ -86,3 +88,82 @@ def test_product_pose_math_equals_oracle_bitwise(oracle):
         assert ok1 == ok2
         assert np.array_equal(i1.view(np.uint32), i2.view(np.uint32))
     assert capi.invert_matrix(np.zeros(16, f32))[0] is False
+
+
+# ---- against the reference's own two functions, compiled as they stand (oracle/_ref/libtsdf_ref_host.so) ------------------
+from oracle.oracle import RefHost  # noqa: E402
+
+needs_ref_host = pytest.mark.skipif(not RefHost.available(), reason="oracle/_ref/libtsdf_ref_host.so not built (make -C oracle ref_host)")
+
+
+def _matrices(rng, n):
+    """Rigid poses, general matrices over many magnitudes, near-singular and exactly singular ones, special values."""
+    out = []
+    for k in range(n):
+        kind = k % 8
+        if kind in (0, 1):
+            m = synth.random_pose(rng, 0.8, 3.0).reshape(4, 4)
+        elif kind == 2:
+            m = rng.standard_normal((4, 4)) * 10.0 ** rng.integers(-6, 7)
+        elif kind == 3:
+            m = rng.standard_normal((4, 4)) * 10.0 ** rng.integers(-6, 7, (4, 4))
+        elif kind == 4:                       # near-singular: two almost equal rows
+            m = rng.standard_normal((4, 4))
+            m[2] = m[1] * (1.0 + rng.standard_normal() * 1e-6)
+        elif kind == 5:                       # exactly singular: det == 0 on the reference's own operation order too
+            m = rng.integers(-3, 4, (4, 4)).astype(np.float64)
+            m[3] = m[0]
+        elif kind == 6:                       # denormals and huge values
+            m = rng.standard_normal((4, 4)) * np.where(rng.random((4, 4)) < 0.5, 1e-40, 1e18)
+        else:                                 # integers: exact arithmetic
+            m = rng.integers(-50, 51, (4, 4)).astype(np.float64)
+        out.append(m.astype(f32).ravel())
+    return out
+
+
+def _same_bits(a, b):
+    return np.array_equal(np.asarray(a, f32).view(np.uint32), np.asarray(b, f32).view(np.uint32))
+
+
+@needs_ref_host
+def test_multiply_equals_the_references_function_bit_for_bit(oracle):
+    ref = RefHost()
+    rng = np.random.default_rng(253)
+    ms = _matrices(rng, 4000)
+    for a, b in zip(ms[::2], ms[1::2]):
+        want = ref.multiply(a, b)
+        assert _same_bits(oracle.multiply(a, b), want) or (np.isnan(want).any() and np.array_equal(np.isnan(oracle.multiply(a, b)), np.isnan(want)))
+        got = capi.multiply_matrix(a, b)
+        assert _same_bits(got, want) or (np.isnan(want).any() and np.array_equal(np.isnan(got), np.isnan(want)))
+
+
+@needs_ref_host
+def test_invert_equals_the_references_function_bit_for_bit(oracle):
+    ref = RefHost()
+    rng = np.random.default_rng(276)
+    n_singular = 0
+    for m in _matrices(rng, 4000):
+        ok_r, inv_r = ref.invert(m)
+        ok_o, inv_o = oracle.invert(m)
+        ok_p, inv_p = capi.invert_matrix(m)
+        assert ok_o == ok_r and ok_p == ok_r
+        if not ok_r:
+            n_singular += 1
+            continue
+        for got in (inv_o, inv_p):
+            nan = np.isnan(inv_r)
+            assert np.array_equal(np.isnan(got), nan) and _same_bits(np.where(nan, 0, got), np.where(nan, 0, inv_r))
+    assert n_singular > 100, "the singular branch (det == 0 -> false, ref: src/tsdf.cu:392-393) should be exercised"
+
+
+@needs_ref_host
+def test_pose_composition_equals_the_references_two_calls(oracle):
+    """TSDF::TSDF inverts the base pose once (ref: src/tsdf.cu:74), TSDF::Integrate multiplies base2world_inv x cam2world
+    (ref: src/tsdf.cu:142): the same two calls on the reference's own functions."""
+    ref = RefHost()
+    rng = np.random.default_rng(142)
+    for _ in range(500):
+        base, cam = synth.random_pose(rng, 0.8, 3.0), synth.random_pose(rng, 0.8, 3.0)
+        ok, inv = ref.invert(base)
+        assert ok
+        assert _same_bits(oracle.cam2base(base, cam), ref.multiply(inv, cam))

@@ -4,7 +4,9 @@ src/Engine.cpp:192-193 masking) of the CPU oracle."""
 import struct
 
 import numpy as np
+import pytest
 
+from oracle.oracle import RefHost
 from semantic_slam_amd import synth
 
 
@@ -54,6 +56,30 @@ def test_ply_format_and_surface_rule(oracle, tmp_path):
     head = (f"ply\nformat binary_little_endian 1.0\nelement vertex {len(pts)}\n"
             "property float x\nproperty float y\nproperty float z\nend_header\n").encode()
     assert raw.startswith(head) and raw[len(head):] == pts.tobytes()
+
+
+@pytest.mark.skipif(not RefHost.available(), reason="oracle/_ref/libtsdf_ref_host.so not built (make -C oracle ref_host)")
+def test_ply_equals_the_references_own_writer_byte_for_byte(oracle, tmp_path):
+    """The oracle's writer against TSDF::SaveVoxelGrid2SurfacePointCloud itself (ref: src/tsdf.cu:170-218, compiled as it
+    stands: oracle/ref_host_driver.cpp), called as ~TSDF calls it (ref: src/tsdf.cu:110-112): the surface rule, the point
+    order, the coordinates' arithmetic and the header, byte for byte -- on an integrated volume and on arrays that hold the
+    rule's edge cases (TSDF +0 / -0 / NaN / denormal, weights around the 0.9 threshold, NaN weights)."""
+    ref = RefHost()
+    rng = np.random.default_rng(170)
+    cases = [small_volume(oracle)]
+    for dims in ((1, 1, 1), (7, 5, 3), (32, 9, 4), (3, 40, 2)):
+        n = dims[0] * dims[1] * dims[2]
+        t = rng.choice(np.array([0.0, -0.0, 1.0, -1.0, 0.25, np.nan, 1e-42, -1e-42, 0.999], np.float32), n).astype(np.float32)
+        w = rng.choice(np.array([0.0, 0.9, np.nextafter(np.float32(0.9), np.float32(1)), np.nextafter(np.float32(0.9), np.float32(0)), 1.0, 37.0,
+                                 np.nan, -1.0], np.float32), n).astype(np.float32)
+        cases.append((dims, 0.013, np.array([-0.31, 0.2, 1.7], np.float32), t, w))
+    cases.append(((4, 4, 4), 0.02, np.zeros(3, np.float32), np.ones(64, np.float32), np.zeros(64, np.float32)))   # no point at all
+    for k, (dims, vs, origin, t, w) in enumerate(cases):
+        a, b = tmp_path / f"oracle{k}.ply", tmp_path / f"ref{k}.ply"
+        oracle.save_ply(str(a), t, w, dims, vs, origin)
+        ref.save_ply(str(b), t, w, dims, vs, origin)
+        assert a.read_bytes() == b.read_bytes(), f"case {k}: dims {dims}"
+        assert len(oracle.surface_points(t, w, dims, vs, origin)) * 12 + len(b.read_bytes().split(b"end_header\n")[0]) + 11 == len(b.read_bytes())
 
 
 def test_object_origin_rule(oracle):
