@@ -9,6 +9,7 @@
 Short runs (--steps 5, no companion legs, no PMC passes, no CPU baseline)."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -50,8 +51,12 @@ def test_one_gpu_line_keeps_the_contract(cuda):
 
 
 def test_two_ranks_as_the_driver_launches_them(cuda):
+    so = socket.socket()
+    so.bind(("127.0.0.1", 0))
+    port = so.getsockname()[1]
+    so.close()
     rc, lines, err = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29571", "bench.py", "--gpus", "2", "--grid", "256"] + QUICK, env={"TSDF_BENCH_BACKEND": "gloo"})
+                          "--master-port", str(port), "bench.py", "--gpus", "2", "--grid", "256"] + QUICK, env={"TSDF_BENCH_BACKEND": "gloo"})
     assert rc == 0, err
     assert len(lines) == 1, "rank 0 alone prints"
     d = json.loads(lines[0])
