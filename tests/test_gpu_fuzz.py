@@ -40,12 +40,37 @@ def random_case(seed):
 @pytest.mark.parametrize("variant", capi.variants(0, 7, 8, 11, 13))
 @pytest.mark.parametrize("seed", range(40))
 def test_random_configuration(cuda, oracle, seed, variant):
+    run_case(cuda, oracle, seed, variant)
+
+
+@pytest.mark.parametrize("seed", range(40, 52))
+def test_random_long_sequences_and_brick_shapes(cuda, oracle, seed):
+    """More frames than one pass holds (runs of claimed frames, a second launch on the same volume, the per-launch
+    decision) over a random valid brick shape."""
+    dims = random_case(seed)[1]
+    run_case(cuda, oracle, seed, 8 if seed % 2 else 0, shape=random_brick_shape(seed, dims), long=True)
+
+
+def random_brick_shape(seed, dims):
+    if dims[0] % 4:
+        return None
+    rs = np.random.default_rng(seed)
+    quads = dims[0] // 4
+    q = int(rs.choice([d for d in range(1, min(quads, 64) + 1) if quads % d == 0]))
+    r = int(rs.integers(1, 64 // q + 1))
+    return q, r, int(rs.integers(1, 64 // (q * r) + 1))
+
+
+def run_case(cuda, oracle, seed, variant, shape=None, long=False):
+    """One random configuration under one kernel variant (tools/fuzz_stress.py runs many more seeds)."""
     rng, dims, h, w, K, vs, origin, trunc, max_depth = random_case(seed)
     base = synth.random_pose(rng, 0.5, 0.5) if seed % 3 else synth.identity_pose()
     cfg = capi.make_config(dims, vs, origin, trunc=trunc, K=K, base2world=base, im_height=h, im_width=w,
                            max_depth=max_depth)
     scene = synth.SurfScene(dims, vs, origin, K=K, h=h, w=w)
     n_frames = int(rng.integers(1, 7))
+    if long:
+        n_frames += 30 + seed % 9
     frames = []
     for k in range(n_frames):
         # mostly cameras that look at the volume from outside, from its boundary or from inside it
@@ -74,9 +99,11 @@ def test_random_configuration(cuda, oracle, seed, variant):
         oracle.integrate(K, c2b, d, dims, origin, vs, trunc, ref_t, ref_w, max_depth=max_depth)
     with capi.Volume(cfg) as vol:
         vol.set_kernel_variant(variant)
+        if shape is not None:
+            vol.set_brick_shape(*shape)
         keep = [(cuda.from_numpy(np.ascontiguousarray(d)).cuda(), None if m is None else cuda.from_numpy(m).cuda())
                 for _, _, d, m in frames]
-        if seed % 2 == 0 and dims[0] % 4 == 0:      # as one fused sequence
+        if (seed % 2 == 0 or long) and dims[0] % 4 == 0:      # as one fused sequence
             vol.integrate_frames_device([d.data_ptr() for d, _ in keep], np.stack([f[0] for f in frames]),
                                         [None if m is None else m.data_ptr() for _, m in keep])
         else:                                       # frame by frame

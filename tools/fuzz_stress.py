@@ -1,30 +1,31 @@
 #!/usr/bin/env python3
-"""Longer run of the randomised parity test (tests/test_gpu_fuzz.py): seeds 40..399 under the four classification variants
-(per launch / always with bricks / always with workgroup patches / never), 1440 configurations, each bit-exact against the
-oracle; the forced-bricks runs draw a random valid brick shape (TSDF_BRICK3D) per seed.  Development probe; the suite itself
-runs seeds 0..39."""
-import sys, os
+"""Longer run of the randomised parity test (tests/test_gpu_fuzz.py): seeds 52..N under the shipped classification variants
+(per launch / always over the brick list / never), the forced runs over a random valid brick shape, every third seed with a
+sequence longer than one pass -- each bit-exact against the oracle.  Development probe; the suite itself runs seeds 0..51.
+    python tools/fuzz_stress.py [last_seed]"""
+import os
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
-import numpy as np, torch
-from oracle.oracle import Oracle
-import test_gpu_fuzz as F
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+from oracle.oracle import Oracle  # noqa: E402
+import test_gpu_fuzz as F  # noqa: E402
+
 orc = Oracle()
-bad = 0
-for seed in range(40, 400):
-    for variant in (0, 8, 11, 7):
-        os.environ.pop("TSDF_BRICK3D", None)
-        dims = F.random_case(seed)[1]
-        if variant == 8 and dims[0] % 4 == 0:
-            rs = np.random.default_rng(seed)
-            quads = dims[0] // 4
-            q = int(rs.choice([d for d in range(1, min(quads, 64) + 1) if quads % d == 0]))
-            r = int(rs.integers(1, 64 // q + 1))
-            sl = int(rs.integers(1, 64 // (q * r) + 1))
-            os.environ["TSDF_BRICK3D"] = f"{q},{r},{sl}"
+last = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+bad = n = 0
+for seed in range(52, last):
+    dims = F.random_case(seed)[1]
+    for variant in (0, 8, 7):
+        shape = F.random_brick_shape(seed, dims) if variant == 8 else None
         try:
-            F.test_random_configuration.__wrapped__(torch, orc, seed, variant) if hasattr(F.test_random_configuration, '__wrapped__') else F.test_random_configuration(torch, orc, seed, variant)
+            F.run_case(torch, orc, seed, variant, shape=shape, long=seed % 3 == 0)
+            n += 1
         except AssertionError as e:
             bad += 1
-            print("FAIL seed", seed, "variant", variant, str(e)[:200], flush=True)
-print("done, failures:", bad)
+            print("FAIL seed", seed, "variant", variant, "shape", shape, str(e)[:200], flush=True)
+    if seed % 50 == 0:
+        print("seed", seed, "cases", n, "failures", bad, flush=True)
+print("done: cases", n, "failures", bad)
