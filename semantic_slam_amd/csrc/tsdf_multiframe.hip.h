@@ -667,26 +667,33 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
             float tv[4] = {t4[r].x, t4[r].y, t4[r].z, t4[r].w};
             float wv[4] = {w4[r].x, w4[r].y, w4[r].z, w4[r].w};
             float num[4], wn[4];
+            // a lane of the wavefront inside the truncation band (dist < 1): its quotient is needed and its value changes, so
+            // the tests for "every quotient is exactly 1" and "no value changed" (three + one compares per voxel) are moot --
+            // the division runs (x / x = 1 where the shortcut would have applied) and the row is stored
+            const bool wave_band = __ballot(bandr[r]) != 0ull;
             bool need = false;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 wn[j] = wv[j] + 1.0f;
                 num[j] = tv[j] * wv[j] + dist[r][j];
-                need |= upd[r][j] && !(num[j] == wn[j] && wn[j] < 3.0e38f && wn[j] > 0.0f);
+            }
+            if (!wave_band) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) need |= upd[r][j] && !(num[j] == wn[j] && wn[j] < 3.0e38f && wn[j] > 0.0f);
             }
             float nt[4];
-            if (__ballot(rowany[r] && need) != 0ull) {
+            if (wave_band || __ballot(rowany[r] && need) != 0ull) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) nt[j] = num[j] / wn[j];
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) nt[j] = 1.0f;
             }
-            bool changed = false, notone = false;
+            bool changed = wave_band, notone = false;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float newt = upd[r][j] ? nt[j] : tv[j];
-                changed |= __float_as_uint(newt) != __float_as_uint(tv[j]);
+                if (!wave_band) changed |= __float_as_uint(newt) != __float_as_uint(tv[j]);
                 notone |= upd[r][j] && __float_as_uint(newt) != 0x3f800000u;
                 tv[j] = newt;
                 wv[j] = upd[r][j] ? wn[j] : wv[j];
