@@ -142,3 +142,27 @@ def test_config2_full_fr3_trajectory_fused(cuda, oracle, variant):
             wv.assert_volume_equals_reference(cuda, f"fr3 trajectory, 194 keyframes into 1024^3 / variant {variant}", vol, ref_t, ref_w, dims)
         _, w_mid = vol.copy_slices(500, 8)
     assert w_mid.max() <= n and np.all(w_mid == np.round(w_mid))
+
+
+@pytest.mark.skipif(not wv.available(), reason="oracle/_ref/libtsdf_ref_hip.so not built")
+def test_config2_fr3_trajectory_through_sensor_noise_and_dropouts(cuda, oracle):
+    """The same 1024^3 volume and trajectory (every other keyframe: 97 frames, four passes) with the frames as a sensor
+    would deliver them -- Gaussian noise (sigma 2 mm), 5 % of every frame dropped in 8 x 8 blocks -- fused over the brick
+    work list (decided per launch): what the depth tile tables may claim changes frame by frame and brick by brick.
+    Every voxel against the reference's own kernel on the same frames."""
+    T = wv.fr3_trajectory(oracle, cuda)
+    cfg, dims = T["cfg"], T["dims"]
+    ks = list(range(0, T["n"], 2))
+    noisy = synth.sensor_imperfections([T["depths"][k] for k in ks], 2.0, 0.05)
+    dev = [cuda.from_numpy(d).cuda() for d in noisy]
+    assert any(np.count_nonzero(d == 0) > np.count_nonzero(T["depths"][k] == 0) for d, k in zip(noisy, ks)), "dropouts expected"
+    wv.drop(f"fr3_1024_{T['n']}")          # the clean replay (8.6 GB) makes room for this one
+    ref_t, ref_w = wv.replay(cuda, "fr3_1024_noisy", cfg.cam_K, dims, cfg.origin, cfg.voxel_size, cfg.trunc_margin,
+                             [T["c2b"][k] for k in ks], dev)
+    assert float(ref_w.max()) > 50
+    with capi.Volume(cfg) as vol:
+        vol.integrate_frames_device([d.data_ptr() for d in dev], T["poses"][ks])
+        info = vol.classification_info()
+        wv.assert_volume_equals_reference(cuda, "fr3 trajectory through noise + dropouts, 97 keyframes into 1024^3", vol, ref_t, ref_w, dims)
+    wv.drop("fr3_1024_noisy")
+    assert info[0] > 0.3, f"claimed fraction {info[0]}: the brick list should still pay through noise and dropouts"
