@@ -166,3 +166,26 @@ def test_sixteen_masked_object_volumes_every_voxel_equals_the_reference_kernel(c
         batch.sync()
         for i, vol in enumerate(batch.volumes):
             wv.assert_volume_equals_reference(cuda, f"object {i} / {path}", vol, refs[i][0], refs[i][1], dims)
+
+
+# ---- one grid over several slab handles in one process (tsdf_group_*): the C++ host's own multi-device shape ----------
+@pytest.mark.parametrize("mode", ["calls", "sequence"])
+def test_512_cube_as_a_group_of_slabs_every_voxel_equals_the_reference_kernel(cuda, mode):
+    """tsdf_group_create over five slab handles (uneven: 512 = 102 + 102 + 103 + 102 + 103 slices; the box has one card, so
+    all on device 0 -- the fan-out, per-slab streams, deferral and global-z indexing are what runs), fed 40 host frames one
+    call at a time (the reference's call, collected per slab) or as one sequence: every voxel of every slab against the
+    same slices of the reference kernel's whole-grid replay."""
+    cfg, dims, poses, dev, host = _workload(cuda, "ssurf")
+    n = 40
+    ref_t, ref_w = wv.replay(cuda, "ssurf512_40", cfg.cam_K, dims, cfg.origin, cfg.voxel_size, cfg.trunc_margin, poses[:n], dev[:n])
+    with capi.Group(cfg, [0, 0, 0, 0, 0]) as grp:
+        if mode == "calls":
+            for p, d in zip(poses[:n], host[:n]):
+                grp.integrate(d, p)
+        else:
+            grp.integrate_frames(host[:n], poses[:n])
+        zs = [(s.cfg.z_begin, s.cfg.z_end) for s in grp.slabs]
+        assert zs[0][0] == 0 and zs[-1][1] == dims[2] and all(a[1] == b[0] for a, b in zip(zs, zs[1:])) and len({b - a for a, b in zs}) == 2
+        for s in grp.slabs:
+            wv.assert_volume_equals_reference(cuda, f"group slab [{s.cfg.z_begin}, {s.cfg.z_end}) / {mode}", s, ref_t, ref_w, dims)
+    wv.drop("ssurf512_40")
