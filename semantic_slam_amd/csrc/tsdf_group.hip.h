@@ -427,12 +427,23 @@ int tsdf_group_save_mesh_ply(tsdf_group *g, const char *path, float weight_thres
 int tsdf_group_save_bin(tsdf_group *g, const char *path)
 {
     if (!g || !path) return fail(TSDF_ERR_INVALID, "tsdf_group_save_bin: NULL argument");
-    const int64_t n = tsdf_group_voxels(g);
-    std::vector<float> host((size_t)(n > 0 ? n : 1));
-    int rc = tsdf_group_download(g, host.data(), nullptr);
+    int rc = group_flush(g);
     if (rc) return rc;
     const tsdf_config &c = g->cfg;
-    return write_bin(path, c.dim_x, c.dim_y, c.dim_z, c.origin, c.voxel_size, c.trunc_margin, host.data(), n, "tsdf_group_save_bin");
+    FILE *fp = std::fopen(path, "wb");
+    if (!fp) return fail(TSDF_ERR_IO, "tsdf_group_save_bin: cannot open %s", path);
+    const float hdr[8] = {(float)c.dim_x, (float)c.dim_y, (float)c.dim_z, c.origin[0], c.origin[1], c.origin[2], c.voxel_size, c.trunc_margin};
+    const bool ok = std::fwrite(hdr, sizeof(float), 8, fp) == 8;
+    // the slabs in z order, each streamed from its own device (the file is the whole grid's: ref src/tsdf.cu:118-131)
+    for (size_t i = 0; ok && rc == TSDF_OK && i < g->slabs.size(); ++i) {
+        tsdf_volume *v = g->slabs[i];
+        if ((rc = bind_device(v)) != TSDF_OK) break;
+        rc = stream_device_to_file(v, fp, v->d_tsdf, (size_t)v->n_vox * sizeof(float), "tsdf_group_save_bin", path);
+    }
+    const int bad = std::fclose(fp);
+    if (rc) return rc;
+    if (!ok || bad) return fail(TSDF_ERR_IO, "tsdf_group_save_bin: short write to %s", path);
+    return TSDF_OK;
 }
 
 }  // extern "C"

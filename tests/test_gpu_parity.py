@@ -482,6 +482,43 @@ def test_checkpoint_resume(cuda, oracle, tmp_path):
             c.load_state(str(tmp_path / "half.state"))   # wrong slab is refused
 
 
+def test_files_larger_than_a_staging_piece_and_a_full_disk(cuda, oracle, tmp_path):
+    """The writers stream device memory to the file in 32 MiB pieces through two pinned buffers: a 256 x 256 x 200 volume
+    (52 MB per array, 63 MB of surface points: more than one piece, the last one partial) gives files byte-identical to the
+    oracle's writers and a checkpoint that loads back bit for bit; a disk that takes no byte (/dev/full) is reported as
+    TSDF_ERR_IO by every writer and leaves the handle usable."""
+    dims, vs = (256, 256, 200), 0.008
+    origin = synth.surf_volume(256, vs, 0.8)
+    cfg = capi.make_config(dims, vs, origin)
+    scene = synth.SurfScene(dims, vs, origin)
+    ref_t, ref_w = oracle.init_grid(dims)
+    with capi.Volume(cfg) as vol:
+        for k in range(3):
+            c2w = scene.pose(4 * k, 16)
+            d = scene.depth(c2w, quantize=True)
+            vol.integrate(d, c2w)
+            oracle.integrate(cfg.cam_K, c2w, d, dims, origin, vs, cfg.trunc_margin, ref_t, ref_w, threads=8)
+        vol.save_ply(str(tmp_path / "a.ply"))
+        vol.save_bin(str(tmp_path / "a.bin"))
+        vol.save_state(str(tmp_path / "a.state"))
+        n_pts = vol.count_surface()
+        assert n_pts * 12 > (32 << 20) and (n_pts * 12) % (32 << 20) != 0, "the point list should span more than one piece, the last one partial"
+        for name, fn in (("save_ply", vol.save_ply), ("save_bin", vol.save_bin), ("save_state", vol.save_state)):
+            with pytest.raises(capi.TsdfError) as e:
+                fn("/dev/full")
+            assert "short write" in str(e.value) or "cannot" in str(e.value), name
+        t, w = vol.download()                               # still usable, nothing changed
+        assert_parity(t, w, ref_t, ref_w)
+    oracle.save_ply(str(tmp_path / "b.ply"), ref_t, ref_w, dims, vs, origin)
+    oracle.save_bin(str(tmp_path / "b.bin"), ref_t, dims, origin, vs, cfg.trunc_margin)
+    assert (tmp_path / "a.ply").read_bytes() == (tmp_path / "b.ply").read_bytes()
+    assert (tmp_path / "a.bin").read_bytes() == (tmp_path / "b.bin").read_bytes()
+    with capi.Volume(cfg) as other:
+        other.load_state(str(tmp_path / "a.state"))
+        t, w = other.download()
+        assert_parity(t, w, ref_t, ref_w)
+
+
 @pytest.mark.parametrize("dims", [(256, 24, 20), (200, 24, 20), (37, 20, 16)])   # row mapping, flat mapping, scalar kernel
 def test_non_finite_depth_samples(cuda, oracle, dims):
     """NaN depth passes both depth tests of the reference (every comparison with NaN is false, ref: src/tsdf.cu:46,49)
