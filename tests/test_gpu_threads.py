@@ -13,7 +13,7 @@ from semantic_slam_amd import capi, synth
 pytestmark = pytest.mark.gpu
 
 
-def test_distinct_handles_from_distinct_threads(cuda, oracle):
+def test_distinct_handles_from_distinct_threads(cuda, oracle, tmp_path):
     dims, vs = (200, 96, 64), 0.004
     n_threads, n_frames = 6, 5
     scene = synth.SurfScene((200, 200, 200), 0.004, np.array([-0.4, -0.4, 0.7], np.float32))
@@ -56,6 +56,9 @@ def test_distinct_handles_from_distinct_threads(cuda, oracle):
                     for p, d in zip(poses, keep):
                         vol.integrate_masked_device(d.data_ptr(), m_dev.data_ptr(), p)
                 results[i] = vol.download()
+                # ... and writes its two files as the object's destructor does (the writers share two staging buffers)
+                vol.save_bin(str(tmp_path / f"tsdf{i}.bin"))
+                vol.save_ply(str(tmp_path / f"tsdf{i}.ply"))
         except Exception as e:   # noqa: BLE001 -- reported by the main thread
             errors.append((i, repr(e)))
 
@@ -70,3 +73,7 @@ def test_distinct_handles_from_distinct_threads(cuda, oracle):
         assert np.array_equal(w, ref_w), f"thread {i}: weights differ"
         assert np.array_equal(t.view(np.uint32), ref_t.view(np.uint32)), f"thread {i}: TSDF differs"
         assert ref_w.sum() > 1000
+        oracle.save_bin(str(tmp_path / "want.bin"), ref_t, dims, cfg.origin, vs, cfg.trunc_margin)
+        oracle.save_ply(str(tmp_path / "want.ply"), ref_t, ref_w, dims, vs, cfg.origin)
+        assert (tmp_path / f"tsdf{i}.bin").read_bytes() == (tmp_path / "want.bin").read_bytes(), f"thread {i}: .bin differs"
+        assert (tmp_path / f"tsdf{i}.ply").read_bytes() == (tmp_path / "want.ply").read_bytes(), f"thread {i}: .ply differs"
