@@ -1081,15 +1081,12 @@ int write_bin(const char *path, int dx, int dy, int dz, const float origin[3], f
 // (files are written rarely and the disk serialises writers anyway); the lock is held for the length of one array.
 struct FileStager {
     std::mutex mu;
-    void *pin[2] = {nullptr, nullptr};
-    hipEvent_t ev[2] = {nullptr, nullptr};
+    void *pin[2] = {nullptr, nullptr};       // portable: any device may copy into them
     static constexpr size_t kPiece = (size_t)32 << 20;
     ~FileStager()
     {
-        for (int i = 0; i < 2; ++i) {
-            if (ev[i]) (void)hipEventDestroy(ev[i]);
+        for (int i = 0; i < 2; ++i)
             if (pin[i]) (void)hipHostFree(pin[i]);
-        }
     }
 };
 FileStager &file_stager() { static FileStager s; return s; }
@@ -1100,23 +1097,29 @@ int stream_device_to_file(tsdf_volume *v, FILE *fp, const void *src, size_t byte
     if (bytes == 0) return TSDF_OK;
     FileStager &fs = file_stager();
     std::lock_guard<std::mutex> lk(fs.mu);
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 2; ++i)
         if (!fs.pin[i]) HIP_TRY(hipHostMalloc(&fs.pin[i], FileStager::kPiece, hipHostMallocPortable));
-        if (!fs.ev[i]) HIP_TRY(hipEventCreateWithFlags(&fs.ev[i], hipEventDisableTiming));
-    }
+    // the events belong to the device of v's stream (the current one: every caller has bound it), so they live for the call
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    hipError_t e = hipEventCreateWithFlags(&ev[0], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[1], hipEventDisableTiming);
     const size_t pieces = (bytes + FileStager::kPiece - 1) / FileStager::kPiece;
     auto len = [&](size_t k) { return k + 1 < pieces ? FileStager::kPiece : bytes - k * FileStager::kPiece; };
     bool short_write = false;
-    for (size_t k = 0; k <= pieces; ++k) {
+    for (size_t k = 0; e == hipSuccess && k <= pieces; ++k) {
         if (k < pieces) {     // piece k on its way ...
-            HIP_TRY(hipMemcpyAsync(fs.pin[k & 1], (const char *)src + k * FileStager::kPiece, len(k), hipMemcpyDeviceToHost, v->stream));
-            HIP_TRY(hipEventRecord(fs.ev[k & 1], v->stream));
+            e = hipMemcpyAsync(fs.pin[k & 1], (const char *)src + k * FileStager::kPiece, len(k), hipMemcpyDeviceToHost, v->stream);
+            if (e == hipSuccess) e = hipEventRecord(ev[k & 1], v->stream);
         }
-        if (k > 0) {          // ... while piece k - 1 is written
-            HIP_TRY(hipEventSynchronize(fs.ev[(k - 1) & 1]));
-            if (!short_write && std::fwrite(fs.pin[(k - 1) & 1], 1, len(k - 1), fp) != len(k - 1)) short_write = true;
+        if (e == hipSuccess && k > 0) {          // ... while piece k - 1 is written
+            e = hipEventSynchronize(ev[(k - 1) & 1]);
+            if (e == hipSuccess && !short_write && std::fwrite(fs.pin[(k - 1) & 1], 1, len(k - 1), fp) != len(k - 1)) short_write = true;
         }
     }
+    if (e != hipSuccess) (void)hipStreamSynchronize(v->stream);     // nothing may still be writing into the buffers
+    for (int i = 0; i < 2; ++i)
+        if (ev[i]) (void)hipEventDestroy(ev[i]);
+    if (e != hipSuccess) return fail(TSDF_ERR_HIP, "%s: %s", who, hipGetErrorString(e));
     if (short_write) return fail(TSDF_ERR_IO, "%s: short write to %s", who, path);
     return TSDF_OK;
 }
