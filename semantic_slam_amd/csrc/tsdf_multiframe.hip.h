@@ -512,7 +512,11 @@ constexpr int kSuperZ = 4;
 // silhouette on its way).  The free-space summary keeps its layout (one word per 256-voxel chunk or row segment, now
 // shared by several wavefronts): a set bit was true for the whole chunk at launch start, each lane only changes its own
 // voxels -- `ones` is per lane here: "the chunk's bit was set and MY quad is still all ones" -- and clearing is idempotent.
-template <int R, bool NT, bool FLAT, bool LABELS = false, bool MASKS = true, bool SHORT = false, bool BRICK = false>
+// EAGER_W (the bricks of a work list: some frame touches them): the weights are requested together with the summary word at the
+// top instead of by the first frame that touches the lane -- one memory round trip less in a wavefront's chain of dependent
+// loads (list entry -> classification tables -> summary word -> quads), which is what the many light wavefronts of a sparse
+// launch spend their time in.
+template <int R, bool NT, bool FLAT, bool LABELS = false, bool MASKS = true, bool SHORT = false, bool BRICK = false, bool EAGER_W = false>
 __device__ __forceinline__ void multi_body(const IntegrateParams &p, const FramePose *__restrict__ frames,
                                            const int n_frames, const int b0, const int b1, const int lz,
                                            const LabelState ls = LabelState(), const unsigned int free_frames = 0u,
@@ -522,6 +526,7 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
     static_assert(!LABELS || R == 1, "label fusion rides on the one-row kernel");
     static_assert(!FLAT || R == 1, "the flat mapping handles one quad per lane");
     static_assert(!BRICK || (R == 1 && !FLAT), "bricks are their own mapping");
+    static_assert(!EAGER_W || BRICK, "eager weights are for the bricks of a work list");
     int xg, gy0;
     size_t row0, flag0;
     // BRICK: the lane's quad as (wave-uniform start of the brick) + (32-bit byte offset of the lane within it).  With ordinary
@@ -604,6 +609,11 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
         w4[r] = make_float4(0.f, 0.f, 0.f, 0.f);
         touched[r] = tchanged[r] = false;
     }
+    bool have_w = false;     // (EAGER_W) the weights are already in registers
+    if constexpr (EAGER_W) {
+        w4[0] = load_quad(false, 0);
+        have_w = true;
+    }
 
     // pose-independent voxel coordinates (ref: src/tsdf.cu:27-29)
     float bxv[4], byv[R];
@@ -626,7 +636,7 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             if (rowany[r] && !touched[r]) {
-                w4[r] = load_quad(false, r);
+                if (!have_w) w4[r] = load_quad(false, r);
                 if (!(fl[r] & 1u)) t4[r] = load_quad(true, r);
                 touched[r] = true;
             }
@@ -727,7 +737,8 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
             const bool all_free = (free_frames >> f) & 1u;
             if (all_free) {
                 // every voxel of the wavefront: valid pixel, diff >= trunc (dist = 1), none in the band
-                if (__ballot(!(touched[0] && ones[0] && (fl[0] & 2u))) == 0ull) {   // steady state of free-space rows: only the weights move
+                if (__ballot(!((touched[0] || have_w) && ones[0] && (fl[0] & 2u))) == 0ull) {   // steady state of free-space rows: only the weights move
+                    touched[0] = true;
                     // ... and a run of such frames moves them by its length at once, when that is the same bits: every
                     // weight an integer below 2^24 - 32, so that each of the run's "+ 1" is exact and so is their sum
                     const unsigned int rest = ~(free_frames >> f);
@@ -1118,7 +1129,7 @@ __global__ __launch_bounds__(256, LABELS ? 6 : TSDF_BRICK_WAVES) void integrate_
             return;
         }
     }
-    multi_body<1, NT, false, LABELS, MASKS, true, true>(mp.common, frames, mp.n_frames, brick, 0, zg, mp.labels, free_frames, skip_frames);
+    multi_body<1, NT, false, LABELS, MASKS, true, true, true>(mp.common, frames, mp.n_frames, brick, 0, zg, mp.labels, free_frames, skip_frames);
 }
 
 // One frame, pose by value (no frame block in memory to stage): what a single tsdf_integrate* call
