@@ -2518,6 +2518,7 @@ static int crossing_pass(tsdf_volume *v, const float *halo_tsdf, const float *ha
     }
     g.n = n; g.dim_x = c.dim_x; g.dim_y = c.dim_y; g.nz = c.z_end - c.z_begin; g.z_begin = c.z_begin;
     g.thr = weight_thresh; g.ox = c.origin[0]; g.oy = c.origin[1]; g.oz = c.origin[2]; g.vs = c.voxel_size;
+    g.flags = v->nseg > 0 ? v->d_flags : nullptr; g.nseg = v->nseg;     // segments that are all free / unseen space are skipped
     if (mesh) hipLaunchKernelGGL(tsdfx::mesh_count, dim3((unsigned)n_chunks), dim3(256), 0, v->stream, g, d_counts);
     else hipLaunchKernelGGL(tsdfx::crossing_count, dim3((unsigned)n_chunks), dim3(256), 0, v->stream, g, d_counts);
     hipLaunchKernelGGL(tsdfx::scan_counts, dim3(1), dim3(1024), 0, v->stream, d_counts, n_chunks, d_offsets, d_total);

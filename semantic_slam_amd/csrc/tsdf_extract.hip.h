@@ -128,7 +128,40 @@ struct CrossingGrid {
     int64_t n;          // voxels in the slab
     int dim_x, dim_y, nz, z_begin;
     float thr, ox, oy, oz, vs;
+    // the free-space summary of the Integrate kernels (one word per 256-voxel row segment, bit 0 = "every TSDF value in here is
+    // exactly 1.0"; rows of nseg segments) or nullptr / 0 when the grid has no row segments
+    const uint32_t *flags;
+    int nseg;
 };
+
+// The 256 voxels starting at linear index seg * 256 and every voxel they are compared with -- the segment's +x, +y, +z
+// neighbours (and with `cube` the +xy, +xz, +yz, +xyz ones) -- are known to hold the value 1.0: no edge changes sign and no cube
+// is cut, so the workgroup skips the segment without reading it.  Most of a fused volume is free or unseen space; the
+// summary is kept exact in that direction by every kernel that writes TSDF values (a cleared bit only costs the reading).
+// Segments of the slab's top slice depend on the halo slice, which has no summary: they are always read.
+__device__ __forceinline__ bool segment_is_flat(const CrossingGrid &g, const int64_t seg, const bool cube)
+{
+    if (g.flags == nullptr || g.nseg <= 0) return false;
+    const int64_t row = seg / g.nseg;                        // lz * dim_y + y
+    const int sx = (int)(seg - row * g.nseg);
+    const int lz = (int)(row / g.dim_y), y = (int)(row - (int64_t)lz * g.dim_y);
+    if (lz >= g.nz || lz + 1 >= g.nz) return false;          // past the slab, or its top slice
+    const bool has_x = sx + 1 < g.nseg, has_y = y + 1 < g.dim_y;
+    const int64_t dy = g.nseg, dz = (int64_t)g.dim_y * g.nseg;
+    uint32_t all = g.flags[seg] & g.flags[seg + dz];
+    if (has_x) all &= g.flags[seg + 1] & g.flags[seg + dz + 1];
+    if (has_y) all &= g.flags[seg + dy] & g.flags[seg + dz + dy];
+    if (cube && has_x && has_y) all &= g.flags[seg + dy + 1] & g.flags[seg + dz + dy + 1];
+    return (all & 1u) != 0u;
+}
+
+// bit k set = segment k of workgroup `chunk` is flat (lane k of every wavefront looks its segment up: one round trip for all 16)
+__device__ __forceinline__ uint32_t flat_segments(const CrossingGrid &g, const int64_t chunk, const bool cube)
+{
+    const int lane = threadIdx.x & 63;
+    const bool f = lane < kPerThread && segment_is_flat(g, chunk * kPerThread + lane, cube);
+    return (uint32_t)__ballot(f);
+}
 
 // bit a set = the edge from voxel i along axis a crosses zero
 __device__ __forceinline__ uint32_t crossing_bits(const CrossingGrid &g, int64_t i, float &t0, float t1[3])
@@ -164,7 +197,9 @@ __global__ __launch_bounds__(256) void crossing_count(CrossingGrid g, uint32_t *
     __shared__ uint32_t wave_sum[4];
     const int64_t base = (int64_t)blockIdx.x * kChunk;
     uint32_t c = 0;
+    const uint32_t flat = flat_segments(g, blockIdx.x, false);
     for (int k = 0; k < kPerThread; ++k) {
+        if ((flat >> k) & 1u) continue;
         float t0, t1[3];
         c += (uint32_t)__popc(crossing_bits(g, base + k * 256 + threadIdx.x, t0, t1));
     }
@@ -180,7 +215,12 @@ __global__ __launch_bounds__(256) void crossing_emit(CrossingGrid g, const int64
     const int64_t base = (int64_t)blockIdx.x * kChunk;
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
+    const uint32_t flat = flat_segments(g, blockIdx.x, false);      // bit k: segment k of the chunk holds nothing (wave-uniform)
     for (int k = 0; k < kPerThread; ++k) {
+        if ((flat >> k) & 1u) {
+            if (lane == 0) cnt[k * 4 + wave] = 0u;
+            continue;
+        }
         float t0, t1[3];
         uint32_t c = (uint32_t)__popc(crossing_bits(g, base + k * 256 + threadIdx.x, t0, t1));
         for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
@@ -196,6 +236,7 @@ __global__ __launch_bounds__(256) void crossing_emit(CrossingGrid g, const int64
     const int64_t slice = (int64_t)g.dim_x * g.dim_y;
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     for (int k = 0; k < kPerThread; ++k) {
+        if ((flat >> k) & 1u) continue;
         const int64_t i = base + k * 256 + threadIdx.x;
         float t0, t1[3];
         const uint32_t bits = crossing_bits(g, i, t0, t1);
@@ -310,7 +351,9 @@ __global__ __launch_bounds__(256) void mesh_count(CrossingGrid g, uint32_t *coun
     __shared__ uint32_t wave_sum[4];
     const int64_t base = (int64_t)blockIdx.x * kChunk;
     uint32_t c = 0;
+    const uint32_t flat = flat_segments(g, blockIdx.x, true);
     for (int k = 0; k < kPerThread; ++k) {
+        if ((flat >> k) & 1u) continue;
         float t[8];
         int x, y, lz;
         if (load_cube(g, base + k * 256 + threadIdx.x, t, x, y, lz)) c += cube_triangle_count(t);
@@ -327,7 +370,12 @@ __global__ __launch_bounds__(256) void mesh_emit_kernel(CrossingGrid g, const in
     const int64_t base = (int64_t)blockIdx.x * kChunk;
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
+    const uint32_t flat = flat_segments(g, blockIdx.x, true);       // bit k: segment k of the chunk holds nothing (wave-uniform)
     for (int k = 0; k < kPerThread; ++k) {
+        if ((flat >> k) & 1u) {
+            if (lane == 0) cnt[k * 4 + wave] = 0u;
+            continue;
+        }
         float t[8];
         int x, y, lz;
         uint32_t c = load_cube(g, base + k * 256 + threadIdx.x, t, x, y, lz) ? cube_triangle_count(t) : 0u;
@@ -342,6 +390,7 @@ __global__ __launch_bounds__(256) void mesh_emit_kernel(CrossingGrid g, const in
     __syncthreads();
     const int64_t chunk_off = offsets[blockIdx.x];
     for (int k = 0; k < kPerThread; ++k) {
+        if ((flat >> k) & 1u) continue;
         float t[8];
         int x, y, lz;
         const bool ok = load_cube(g, base + k * 256 + threadIdx.x, t, x, y, lz);
