@@ -54,3 +54,42 @@ def test_crossings_across_slabs_need_and_use_the_halo(cuda, oracle):
     assert len(np.concatenate(parts_nohalo)) < len(whole), "the scene must have crossings on slab boundaries"
     for v in vols:
         v.close()
+
+
+def test_flat_segments_are_skipped_only_where_nothing_can_cross(cuda, oracle):
+    """Grids with 256-voxel row segments (512-wide rows: two per row) take the early-out of the crossing and mesh kernels: a
+    segment is skipped unread when the free-space summary says that it and every segment it is compared with hold 1.0.
+    (a) a fused scene: crossings and mesh equal the oracle's, in three slabs with halos as well;  (b) uploaded volumes that
+    are 1.0 everywhere except one voxel placed so that the sign change belongs to a NEIGHBOUR of the segment that holds it
+    -- the last voxel of a segment (its -x neighbour's edge ends there... its own +x edge leaves the segment), the first
+    voxel of a row, of a slice, of the next segment -- each must still produce exactly the oracle's vertices and triangles."""
+    dims, vs = (512, 24, 12), 0.004
+    origin, vols, ref_t, ref_w = fused_scene(cuda, oracle, dims, vs, [0, 5, 12])
+    whole_x = oracle.zero_crossings(ref_t, ref_w, dims[:2], 0, dims[2], vs, origin)
+    whole_m = oracle.mesh_triangles(ref_t, ref_w, dims[:2], 0, dims[2], vs, origin)
+    assert len(whole_x) > 300 and len(whole_m) > 300
+    px, pm = [], []
+    for i, v in enumerate(vols):
+        halo = vols[i + 1].copy_slices(0, 1) if i + 1 < len(vols) else None
+        px.append(v.extract_crossings(halo))
+        pm.append(v.extract_mesh(halo))
+        v.close()
+    assert np.array_equal(np.concatenate(px).view(np.uint32), whole_x.view(np.uint32))
+    assert np.array_equal(np.concatenate(pm).view(np.uint32), whole_m.view(np.uint32))
+
+    cfg = capi.make_config(dims, vs, origin)
+    n = dims[0] * dims[1] * dims[2]
+    slice_ = dims[0] * dims[1]
+    spots = [(255, 3, 2), (256, 3, 2), (0, 4, 2), (511, 4, 2), (17, 0, 3), (17, 23, 3), (300, 5, 0), (300, 5, 11), (255, 23, 10), (256, 0, 1)]
+    with capi.Volume(cfg) as vol:
+        for x, y, z in spots:
+            t = np.ones(n, np.float32)
+            w = np.ones(n, np.float32)
+            t[z * slice_ + y * dims[0] + x] = -0.5
+            vol.upload(t, w)
+            want_x = oracle.zero_crossings(t, w, dims[:2], 0, dims[2], vs, origin)
+            want_m = oracle.mesh_triangles(t, w, dims[:2], 0, dims[2], vs, origin)
+            assert len(want_x) >= 3, (x, y, z)
+            got_x, got_m = vol.extract_crossings(), vol.extract_mesh()
+            assert got_x.shape == want_x.shape and np.array_equal(got_x.view(np.uint32), want_x.view(np.uint32)), (x, y, z)
+            assert got_m.shape == want_m.shape and np.array_equal(got_m.view(np.uint32), want_m.view(np.uint32)), (x, y, z)
