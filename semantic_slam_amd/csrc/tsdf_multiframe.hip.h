@@ -984,7 +984,7 @@ __global__ __launch_bounds__(256, R == 2 ? 6 : 1) void integrate_multi_inline(Mu
 // + a classification in integrate_multi_inline's prologue) kept 5.4 of 8 wavefront slots per SIMD occupied, many of them by
 // wavefronts on their way out, and the dispatcher walked through long runs of dead workgroups while finished slots stayed
 // empty.  Now the Integrate launch only ever sees the bricks of super-bricks that some frame may touch:
-//   classify_brick_list   one WAVEFRONT per super-brick = kSuperBX x kSuperBY x kSuperBZ bricks (16 x 8 x 16 voxels with
+//   classify_brick_list   one WAVEFRONT per super-brick = kSuperBX x kSuperBY x kSuperBZ bricks (32 x 8 x 8 voxels with
 //                         the default 8 x 4 x 8-voxel brick), one frame per lane (paired half-waves: classify_patch<true>)
 //                         on the super-brick's box.  Skipped by every frame: nothing is emitted.  Otherwise its bricks are
 //                         appended to the work list -- ONE atomic per wavefront, one 16-byte entry per brick from as many
@@ -999,14 +999,17 @@ __global__ __launch_bounds__(256, R == 2 ? 6 : 1) void integrate_multi_inline(Mu
 // box): the Integrate kernel of a 32-frame launch 1.132 -> 0.93 ms on S-surf 512^3, 5.89 -> 4.84 ms on the fr3 trajectory
 // at 1024^3.  (A pre-pass that also classified every brick -- so that no wavefront would ever be launched to leave -- cost
 // more than that saves: 0.20 ms and 2.1 ms per launch, sixteen dependent classifications per wavefront.)
-// Bricks per super-brick along x, y (row groups), z (slice groups): 2 x 2 x 2.  A smaller box is decided more often (fewer
-// bricks left to classify themselves, fewer listed at all) but costs a pre-pass wavefront per box; a workgroup of
-// integrate_brick_list takes four consecutive entries of a sub-list -- two x-neighbours of two row groups -- whose 32-byte row
-// pieces meet in L2 (the stores go through buffer descriptors and leave as whole lines either way).  Measured, same box, ms per
-// frame on S-surf 512^3 / the fr3 trajectory 1024^3 / S-surf 200^3:  4x2x2 0.0320 / 0.1610 / 0.00608;  2x2x2 0.0306 / 0.1600 /
-// 0.00585;  2x4x2 0.0314 / 0.1594 / 0.00587;  4x1x2 0.0312 / 0.1612 / 0.00570;  2x2x1 0.0312 / 0.1654 / 0.00560;  2x1x2 0.0310 /
-// 0.1680 / 0.00581;  4x4x2, 4x2x4, 8x2x2 0.0347-0.0353 / 0.165;  1x1x1 (every brick classified by the pre-pass) 0.0384 / 0.232.
-constexpr int kSuperBX = 2, kSuperBY = 2, kSuperBZ = 2;
+// Bricks per super-brick along x, y (row groups), z (slice groups): 4 x 2 x 1 (32 x 8 x 8 voxels).  A smaller box is decided
+// more often (fewer bricks left to classify themselves, fewer listed at all) but costs a pre-pass wavefront per box; four along
+// x because a workgroup of integrate_brick_list takes four consecutive entries of a sub-list -- then the four x-neighbours of one
+// row group and slice group, whose 32-byte row pieces make up whole 128-byte lines.  Measured, same box, ms per frame on the
+// all-free-space launch / S-surf 512^3 / the fr3 trajectory 1024^3 / S-surf 200^3, and S-surf's HBM bytes per launch:
+//   4x2x2  0.0095 / 0.0321 / 0.1614 / 0.00608   982 MB        4x2x1  0.0101 / 0.0312 / 0.1607 / 0.00585   975 MB
+//   4x1x2  0.0101 / 0.0312 / 0.1614 / 0.00570   994 MB        4x1x1  0.0113 / 0.0320 / 0.1676 / 0.00578   932 MB
+//   2x2x2  0.0113 / 0.0307 / 0.1600 / 0.00584  1245 MB (two x-neighbours per workgroup: half lines, a quarter more traffic
+//   for 1.6 % of S-surf's time);  2x4x2 0.0314 / 0.1594;  2x2x1 0.0312 / 0.1654;  2x1x2 0.0310 / 0.1680;  4x4x2, 4x2x4, 8x2x2
+//   0.0347-0.0353 / 0.165;  1x1x1 (every brick classified by the pre-pass) 0.0384 / 0.232.
+constexpr int kSuperBX = 4, kSuperBY = 2, kSuperBZ = 1;
 constexpr int kSuperBricks = kSuperBX * kSuperBY * kSuperBZ;
 static_assert(kSuperBricks <= 32, "one lane of a half-wave per brick of the super-brick");
 constexpr unsigned int kBrickUndecided = 0x80000000u;     // list entry flag: the brick has to classify itself
