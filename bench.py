@@ -70,6 +70,7 @@ def parse():
                          "exit code must say so: 4 / 3)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="single-GPU rehearsal of one rank of an N-GPU job: integrate only rank 0's z-slab of N")
+    ap.add_argument("--emulate-rank", type=int, default=0, help="with --emulate-world N: which rank's z-slab (default 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the contract's timed region (for profiler runs: no companion legs, which launch more kernels)")
@@ -418,7 +419,8 @@ def main():
     Dz = dims[2]
     zb, ze = rank * Dz // world, (rank + 1) * Dz // world
     if args.emulate_world > 1 and world == 1:
-        zb, ze = 0, Dz // args.emulate_world
+        assert 0 <= args.emulate_rank < args.emulate_world
+        zb, ze = args.emulate_rank * Dz // args.emulate_world, (args.emulate_rank + 1) * Dz // args.emulate_world
     n_global = dims[0] * dims[1] * dims[2]
     cfg = capi.make_config(dims, vs, W.origin, trunc=W.trunc, base2world=W.base2world, z_begin=zb, z_end=ze, device=local_rank)
     vol = capi.Volume(cfg)

@@ -87,3 +87,17 @@ def test_a_dead_wire_shows_in_the_exit_code(cuda, fault, code):
     assert "error" in d["extraction"] and d["extraction_hung"] is (fault == "hang")
     assert d["multi_gpu"]["halo_and_extraction_ran"] is False
     assert d["value"] > 0
+
+
+@pytest.mark.parametrize("world,rank_", [(2, 1), (4, 3), (8, 0), (8, 5), (8, 7)])
+def test_every_ranks_slab_of_the_weak_scaling_grids_keeps_the_headlines_promise(cuda, world, rank_):
+    """The driver's N = 2, 4, 8 runs give every rank one z-slab of a grid that grows with N inside the same physical box
+    (512 x 512 x 1024 ... 1024^3).  The line's assertions -- every voxel of the slab updated by every frame, every TSDF value
+    inside the truncation band -- must hold for ANY rank's slab, not only rank 0's: rehearsed here slab by slab on one GPU
+    (`--emulate-world N --emulate-rank r`; an assertion that fails is a non-zero exit)."""
+    rc, lines, err = run([sys.executable, "bench.py", "--emulate-world", str(world), "--emulate-rank", str(rank_)] + QUICK)
+    assert rc == 0, err
+    d = json.loads(lines[0])
+    assert d["roofline"]["units_per_launch"] == 512 ** 3 and 0.3 < d["roofline"]["frac"] <= 1.0
+    assert d["config"]["grid"] == {2: [512, 512, 1024], 4: [512, 1024, 1024], 8: [1024, 1024, 1024]}[world]
+    assert f"of {d['config']['grid'][2] // world} slices" in d["config"]["partition"]
