@@ -41,3 +41,14 @@ def test_default_brick_shape_respects_thin_slabs_and_short_columns():
     assert (q, r, s) == (1, 1, 1)
     with pytest.raises(capi.TsdfError, match="tsdf_default_brick_shape"):
         shape_of((0, 4, 4))
+
+
+def test_default_brick_shape_keeps_a_bricks_span_below_4_GiB():
+    """The brick kernels address a lane's quad as (start of the brick) + (32-bit byte offset): a brick of s slices spans
+    s * dim_x * dim_y voxels, which must stay below 2^30 (csrc/tsdf_capi.hip, brick_shape_ok).  Slices of 2^28 voxels allow at
+    most three slices per brick; slices of 2^30 voxels allow none, and the grid gets no brick view (the per-voxel launch)."""
+    q, r, s = shape_of((16384, 16384, 8))
+    assert 1 <= s <= 3 and q * r * s <= 64 and s * 16384 * 16384 < 2 ** 30
+    assert shape_of((32768, 32768, 1)) == (0, 0, 1) or shape_of((32768, 32768, 1))[0] == 0
+    q, r, s = shape_of((8192, 8192, 64))                     # 2^26 per slice: the usual eight slices still fit
+    assert (q, r, s) == (2, 4, 8)
