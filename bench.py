@@ -264,13 +264,21 @@ def cpu_baseline(args, W, cam_K, trunc):
 # ------------------------------------------------------------------------------------------------------------
 # roofline.traffic, measured by this run: two short rocprofv3 --pmc passes over a child run of this script
 # ------------------------------------------------------------------------------------------------------------
-def _pmc_pass(counters, kernel_substr, child_args, keep, timeout=300):
+_PMC_BROKEN = None     # reason of the first failed pass: the remaining passes of the run are skipped (a profiler that does not work
+                       # here must cost the line one time-out, not one per pass)
+
+
+def _pmc_pass(counters, kernel_substr, child_args, keep, timeout=150):
     """One `rocprofv3 --pmc <counters>` pass over a short child run of this script (`--pmc-child`: the launches only).
     Returns ({counter: (mean over the kernel's last `keep` dispatches -- the child's timed part; its warm-up launch may have
     taken another kernel -- , dispatches)}, None) or (None, reason)."""
+    global _PMC_BROKEN
+    if _PMC_BROKEN is not None:
+        return None, "skipped after an earlier pass failed: " + _PMC_BROKEN
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
-        return None, "rocprofv3 not found"
+        _PMC_BROKEN = "rocprofv3 not found"
+        return None, _PMC_BROKEN
     tmp = os.environ.get("TMPDIR") or "/tmp"
     d = tempfile.mkdtemp(prefix="bench_pmc_", dir=tmp)
     cmd = [exe, "--pmc"] + list(counters) + ["-d", d, "-o", "p", "--output-format", "csv", "--",
@@ -282,7 +290,8 @@ def _pmc_pass(counters, kernel_substr, child_args, keep, timeout=300):
         p = subprocess.run(cmd, cwd=tmp, env=env, timeout=timeout, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
         files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
         if p.returncode != 0 or not files:
-            return None, f"rocprofv3 --pmc {' '.join(counters)} failed (rc {p.returncode}): {p.stderr.decode(errors='replace')[-200:]}"
+            _PMC_BROKEN = f"rocprofv3 --pmc {' '.join(counters)} failed (rc {p.returncode}): {p.stderr.decode(errors='replace')[-200:]}"
+            return None, _PMC_BROKEN
         out = {}
         rows = [r for r in csv.DictReader(open(files[0])) if kernel_substr in r["Kernel_Name"]]
         for c in counters:
@@ -293,7 +302,8 @@ def _pmc_pass(counters, kernel_substr, child_args, keep, timeout=300):
             out[c] = (float(np.mean(v)), len(v))
         return out, None
     except Exception as e:   # noqa: BLE001 -- the counters are optional, the bench line is not
-        return None, f"rocprofv3 --pmc {' '.join(counters)}: {e!r}"[:300]
+        _PMC_BROKEN = f"rocprofv3 --pmc {' '.join(counters)}: {e!r}"[:300]
+        return None, _PMC_BROKEN
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
