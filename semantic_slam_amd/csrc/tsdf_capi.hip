@@ -134,6 +134,7 @@ struct tsdf_volume {
     int chunks_per_slice;  // ceil(dim_x*dim_y / 256)
     bool flat;             // dim_x % 256 != 0: summary-maintaining launches use the flat mapping
     int brick_q, brick_r, brick_s;   // wavefront brick of the classified launches (choose_brick / tsdf_set_brick_shape); q = 0: none
+    int tile;                        // pixels per edge of the depth tiles of this handle's classified launches (tile_edge_for)
     bool flags_known_zero;
     unsigned int *d_super;       // per super-brick frame words of the current fused brick launch (classify_superbricks)
     size_t super_words;
@@ -408,8 +409,9 @@ tsdfk::IntegrateParams make_params(const tsdf_volume *v, const float *depth_dev,
         p.cz_short = sok ? (float)(std::fmax(bmax / 64.0, eps / 3.2e-5) * 1.0001) : 3.0e38f;
         p.cz_pad = sok ? (float)(std::fmax(2.0 * eps, (double)p.cz_margin) * 1.0001) : 3.0e38f;
     }
-    p.tiles_w = (c.im_width + tsdfk::kTile - 1) / tsdfk::kTile;
-    p.tiles_h = (c.im_height + tsdfk::kTile - 1) / tsdfk::kTile;
+    p.tiles_w = (c.im_width + v->tile - 1) / v->tile;
+    p.tiles_h = (c.im_height + v->tile - 1) / v->tile;
+    p.tile_inv = 1.0f / (float)v->tile;
     // 0.5 (rounding to the pixel) + 1 (slack) + the projection error for cz >= cz_short: |fx| * (eps / cz) * (1 + |t|)
     // with eps / cz <= 3.2e-5 and |t| <= 4 (W + |cx|) / |fx| for every corner that can matter
     p.px_margin_u = (float)(1.5 + 3.2e-5 * (std::fabs((double)p.fx) + 4.0 * (c.im_width + std::fabs((double)p.cx))));
@@ -443,6 +445,19 @@ size_t tile_table_elems_host(int tiles_w, int tiles_h)
 
 bool tiles_fit(const tsdfk::IntegrateParams &p) { return (int64_t)p.tiles_w * p.tiles_h <= 16384; }
 
+// Pixels per depth tile edge for a slab: 8 where a fused launch is long enough to repay tables four times as large (the finer
+// tiles leave a fifth fewer wavefront-frames to the per-voxel path: tsdf_multiframe.hip.h), 16 otherwise and wherever the finer
+// grid of tiles would not fit the table kernels.  The break-even lies between 200^3 (8 M voxels: 16 is 20 % faster) and 512^3
+// (134 M: 8 is 10 % faster) at about 60 M voxels; members of a batch share one table layout and keep 16.
+constexpr int64_t kFineTileMinVoxels = 48000000;
+thread_local bool g_create_for_batch = false;
+int tile_edge_for(const tsdf_config &c)
+{
+    const int64_t n = (int64_t)c.dim_x * c.dim_y * (int64_t)(c.z_end - c.z_begin);
+    const int64_t fine_tiles = (int64_t)((c.im_width + 7) / 8) * ((c.im_height + 7) / 8);
+    return (!g_create_for_batch && n >= kFineTileMinVoxels && fine_tiles <= tsdfk::kTileLdsEntries) ? 8 : 16;
+}
+
 // One-frame masked launches are classified per workgroup when the launch is large enough to repay the three small
 // dependent dispatches ahead of it (tile summary, sparse table, class table: ~25 us on the stream).  Measured
 // (tools/batch_time.py, instance masks over 12 % of the image): 16 x 200^3 batched 0.275 -> 0.157 ms per frame (wavefront
@@ -472,11 +487,13 @@ int build_tile_tables(hipStream_t stream, const tsdf_config &c, const tsdfk::Int
         tp.tiles = tables + (size_t)k * per;
         tp.H = c.im_height; tp.W = c.im_width; tp.tiles_w = p.tiles_w; tp.tiles_h = p.tiles_h;
         tp.max_depth = c.max_depth;
-        if (tsdfk::kTile == 16) {   // whole-row reads: one wavefront per strip of four tiles
+        // whole-row reads: one wavefront per strip of 64 pixels (four 16-pixel tiles or eight 8-pixel ones)
+        if (p.tile_inv == 0.0625f) {
             const int strips = ((p.tiles_w + 3) / 4) * p.tiles_h;
-            hipLaunchKernelGGL(tsdfk::depth_tile_summary, dim3((unsigned)((strips + 3) / 4), m), dim3(64, 4), 0, stream, tp);
+            hipLaunchKernelGGL(tsdfk::depth_tile_summary<16>, dim3((unsigned)((strips + 3) / 4), m), dim3(64, 4), 0, stream, tp);
         } else {
-            hipLaunchKernelGGL(tsdfk::depth_tile_summary_per_tile, dim3((unsigned)((p.tiles_w * p.tiles_h + 3) / 4), m), dim3(64, 4), 0, stream, tp);
+            const int strips = ((p.tiles_w + 7) / 8) * p.tiles_h;
+            hipLaunchKernelGGL(tsdfk::depth_tile_summary<8>, dim3((unsigned)((strips + 3) / 4), m), dim3(64, 4), 0, stream, tp);
         }
         if (p.tiles_w * p.tiles_h <= tsdfk::kTileLdsEntries) {
             hipLaunchKernelGGL(tsdfk::tile_sparse_table, dim3((unsigned)tile_levels_host(p.tiles_w), m), dim3(256), 0, stream, tp.tiles,
@@ -1224,8 +1241,9 @@ int tsdf_create(const tsdf_config *cfg, tsdf_volume **out)
         return cleanup(fail(TSDF_ERR_HIP, "tsdf_create: hipMalloc of the summary: %s", hipGetErrorString(e)));
     // staging, deferral and tile-table memory: the store shared by every handle of this device and image size (nothing is
     // allocated until a frame arrives)
+    v->tile = tile_edge_for(*cfg);
     {
-        const int tw = (cfg->im_width + tsdfk::kTile - 1) / tsdfk::kTile, th = (cfg->im_height + tsdfk::kTile - 1) / tsdfk::kTile;
+        const int tw = (cfg->im_width + v->tile - 1) / v->tile, th = (cfg->im_height + v->tile - 1) / v->tile;
         const size_t table_bytes = (int64_t)tw * th <= 16384 ? tsdfk::kMaxFramesPerLaunch * tile_table_elems_host(tw, th) * sizeof(float2) : 0;
         if ((e = tsdf_store::store_ref(cfg->device, (size_t)cfg->im_height * cfg->im_width, table_bytes, &v->store)) != hipSuccess ||
             (e = hipEventCreateWithFlags(&v->flush_done[0], hipEventDisableTiming)) != hipSuccess ||
@@ -1756,41 +1774,47 @@ int tsdf_selftest_tile_tables(int32_t device, const float *depth_dev, const uint
     if (!depth_dev || !mismatches || im_height <= 0 || im_width <= 0)
         return fail(TSDF_ERR_INVALID, "tsdf_selftest_tile_tables: bad argument");
     HIP_TRY(hipSetDevice(device));
-    const int tw = (im_width + tsdfk::kTile - 1) / tsdfk::kTile, th = (im_height + tsdfk::kTile - 1) / tsdfk::kTile;
-    const size_t per = tile_table_elems_host(tw, th);
-    float2 *d_a = nullptr, *d_b = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_a, per * sizeof(float2)));
-    if (hipMalloc((void **)&d_b, per * sizeof(float2)) != hipSuccess) { (void)hipFree(d_a); return fail(TSDF_ERR_HIP, "tsdf_selftest_tile_tables: hipMalloc"); }
-    (void)hipMemset(d_a, 0xff, per * sizeof(float2));
-    (void)hipMemset(d_b, 0x7f, per * sizeof(float2));
-    tsdfk::TileSummaryParams tp;
-    for (int f = 0; f < tsdfk::kMaxFramesPerLaunch; ++f) { tp.depth[f] = depth_dev; tp.mask[f] = mask_dev; }
-    tp.H = im_height; tp.W = im_width; tp.tiles_w = tw; tp.tiles_h = th; tp.max_depth = max_depth;
-    const unsigned lj = (unsigned)tile_levels_host(tw);
-    // a: the kernels the library launches (strips of four tiles, doubling in LDS when the frame's tiles fit)
-    tp.tiles = d_a;
-    if (tsdfk::kTile == 16)
-        hipLaunchKernelGGL(tsdfk::depth_tile_summary, dim3((unsigned)((((tw + 3) / 4) * th + 3) / 4), 1), dim3(64, 4), 0, 0, tp);
-    else
-        hipLaunchKernelGGL(tsdfk::depth_tile_summary_per_tile, dim3((unsigned)((tw * th + 3) / 4), 1), dim3(64, 4), 0, 0, tp);
-    if (tw * th <= tsdfk::kTileLdsEntries)
-        hipLaunchKernelGGL(tsdfk::tile_sparse_table, dim3(lj, 1), dim3(256), 0, 0, d_a, tw, th, (unsigned long long *)nullptr);
-    else
-        hipLaunchKernelGGL(tsdfk::tile_sparse_table_scan, dim3(lj, 1), dim3(256), 0, 0, d_a, tw, th);
-    // b: one wavefront per tile, levels by scanning
-    tp.tiles = d_b;
-    hipLaunchKernelGGL(tsdfk::depth_tile_summary_per_tile, dim3((unsigned)((tw * th + 3) / 4), 1), dim3(64, 4), 0, 0, tp);
-    hipLaunchKernelGGL(tsdfk::tile_sparse_table_scan, dim3(lj, 1), dim3(256), 0, 0, d_b, tw, th);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipDeviceSynchronize();
-    std::vector<float2> a(per), b(per);
-    if (e == hipSuccess) e = hipMemcpy(a.data(), d_a, per * sizeof(float2), hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(b.data(), d_b, per * sizeof(float2), hipMemcpyDeviceToHost);
-    (void)hipFree(d_a);
-    (void)hipFree(d_b);
-    if (e != hipSuccess) return fail(TSDF_ERR_HIP, "tsdf_selftest_tile_tables: %s", hipGetErrorString(e));
     uint64_t bad = 0;
-    for (size_t i = 0; i < per; ++i) bad += std::memcmp(&a[i], &b[i], sizeof(float2)) != 0;
+    for (const int tile : {16, 8}) {      // both tile sizes the library uses (tile_edge_for)
+        const int tw = (im_width + tile - 1) / tile, th = (im_height + tile - 1) / tile;
+        if ((int64_t)tw * th > 16384) continue;
+        const size_t per = tile_table_elems_host(tw, th);
+        float2 *d_a = nullptr, *d_b = nullptr;
+        HIP_TRY(hipMalloc((void **)&d_a, per * sizeof(float2)));
+        if (hipMalloc((void **)&d_b, per * sizeof(float2)) != hipSuccess) { (void)hipFree(d_a); return fail(TSDF_ERR_HIP, "tsdf_selftest_tile_tables: hipMalloc"); }
+        (void)hipMemset(d_a, 0xff, per * sizeof(float2));
+        (void)hipMemset(d_b, 0x7f, per * sizeof(float2));
+        tsdfk::TileSummaryParams tp;
+        for (int f = 0; f < tsdfk::kMaxFramesPerLaunch; ++f) { tp.depth[f] = depth_dev; tp.mask[f] = mask_dev; }
+        tp.H = im_height; tp.W = im_width; tp.tiles_w = tw; tp.tiles_h = th; tp.max_depth = max_depth;
+        const unsigned lj = (unsigned)tile_levels_host(tw);
+        // a: the kernels the library launches (strips of 64 pixels; doubling in LDS when the frame's tiles fit)
+        tp.tiles = d_a;
+        if (tile == 16)
+            hipLaunchKernelGGL(tsdfk::depth_tile_summary<16>, dim3((unsigned)((((tw + 3) / 4) * th + 3) / 4), 1), dim3(64, 4), 0, 0, tp);
+        else
+            hipLaunchKernelGGL(tsdfk::depth_tile_summary<8>, dim3((unsigned)((((tw + 7) / 8) * th + 3) / 4), 1), dim3(64, 4), 0, 0, tp);
+        if (tw * th <= tsdfk::kTileLdsEntries)
+            hipLaunchKernelGGL(tsdfk::tile_sparse_table, dim3(lj, 1), dim3(256), 0, 0, d_a, tw, th, (unsigned long long *)nullptr);
+        else
+            hipLaunchKernelGGL(tsdfk::tile_sparse_table_scan, dim3(lj, 1), dim3(256), 0, 0, d_a, tw, th);
+        // b: one wavefront per tile, levels by scanning
+        tp.tiles = d_b;
+        if (tile == 16)
+            hipLaunchKernelGGL(tsdfk::depth_tile_summary_per_tile<16>, dim3((unsigned)((tw * th + 3) / 4), 1), dim3(64, 4), 0, 0, tp);
+        else
+            hipLaunchKernelGGL(tsdfk::depth_tile_summary_per_tile<8>, dim3((unsigned)((tw * th + 3) / 4), 1), dim3(64, 4), 0, 0, tp);
+        hipLaunchKernelGGL(tsdfk::tile_sparse_table_scan, dim3(lj, 1), dim3(256), 0, 0, d_b, tw, th);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        std::vector<float2> a(per), b(per);
+        if (e == hipSuccess) e = hipMemcpy(a.data(), d_a, per * sizeof(float2), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(b.data(), d_b, per * sizeof(float2), hipMemcpyDeviceToHost);
+        (void)hipFree(d_a);
+        (void)hipFree(d_b);
+        if (e != hipSuccess) return fail(TSDF_ERR_HIP, "tsdf_selftest_tile_tables: %s", hipGetErrorString(e));
+        for (size_t i = 0; i < per; ++i) bad += std::memcmp(&a[i], &b[i], sizeof(float2)) != 0;
+    }
     *mismatches = bad;
     return TSDF_OK;
 }
@@ -2245,7 +2269,9 @@ int tsdf_batch_create(const tsdf_config *cfgs, int32_t n, tsdf_batch **out)
     std::vector<int2> map;
     for (int i = 0; i < n; ++i) {
         tsdf_volume *v = nullptr;
+        g_create_for_batch = true;        // one table layout for all members (tile_edge_for)
         int rc = tsdf_create(&cfgs[i], &v);
+        g_create_for_batch = false;
         if (rc) return cleanup(rc);
         b->vols.push_back(v);
         const int nz = cfgs[i].z_end - cfgs[i].z_begin;

@@ -74,6 +74,7 @@ struct IntegrateParams {
     // the brick work list's {super-bricks skipped by every frame, entries, entries left to classify themselves, of those:
     // skipped by every frame} (tsdf_brick_list_stats).
     int tiles_w, tiles_h;
+    float tile_inv;           // 1 / (pixels per tile edge): 1/16, or 1/8 for slabs large enough to repay the finer tables
     float px_margin_u, px_margin_v;
     unsigned int *shortcut_stats;
     float cz_short, cz_pad;   // per pose; copied into FramePose (see there)

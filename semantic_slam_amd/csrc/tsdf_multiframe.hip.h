@@ -38,15 +38,15 @@ struct FramePose {
 };
 
 // ---- depth tile summaries ---------------------------------------------------------------------------------
-// Per 16 x 16 pixel tile of a depth frame: x = the smallest depth if EVERY pixel of the tile passes the
-// reference's depth-range test (0 < d <= max_depth, ref: src/tsdf.cu:46), else -inf; y = the largest depth among
-// the pixels that pass it, -inf if none does.  A NaN anywhere in the tile (NaN passes the reference's tests and
-// updates the voxel) makes the tile claim nothing: (-inf, +inf).
-#ifndef TSDF_TILE
-#define TSDF_TILE 16   /* pixels per tile edge: 16, or 8 for A/B builds (measured: the 4x larger tables cost more to build than their tighter ranges save -- 512^3 S-surf 0.0431 -> 0.0440 ms/frame, 16 x 200^3 masked 0.145 -> 0.277) */
-#endif
-constexpr int kTile = TSDF_TILE;
-
+// Per tile of a depth frame (16 x 16 pixels, or 8 x 8: the host chooses per slab, see tile_edge_for): x = the smallest depth
+// if EVERY pixel of the tile passes the reference's depth-range test (0 < d <= max_depth, ref: src/tsdf.cu:46), else -inf;
+// y = the largest depth among the pixels that pass it, -inf if none does.  A NaN anywhere in the tile (NaN passes the
+// reference's tests and updates the voxel) makes the tile claim nothing: (-inf, +inf).
+// Finer tiles bound a box's depths more tightly -- S-surf 512^3: 11.6 % of the wavefront-frames are left to the per-voxel
+// path instead of 14.9 % -- but their tables are four times as large (640 x 480: 1.6 MB per frame instead of 0.29 MB).  With
+// the brick work list that pays for large slabs (512^3 S-surf 0.0313 -> 0.0281 ms per frame, through noise and dropouts
+// 0.0408 -> 0.0354, the 1024^3 trajectory 0.161 -> 0.152) and costs on small ones (200^3: 0.0059 -> 0.0070; round 2, before
+// the list: 512^3 0.0431 -> 0.0440, 16 x 200^3 masked 0.145 -> 0.277).
 // Counters of a classified fused launch, sharded: one word saturates at about 88 returning device-scope atomics per
 // microsecond (MI355X_MICROARCH.md, "dequeue"; measured here: one list head for the 262 144 super-bricks of a 1024^3 slab
 // made the pre-pass 1.7 ms instead of 0.13), so the brick work list is kListBuckets sub-lists with a head each, 256 bytes
@@ -54,7 +54,6 @@ constexpr int kTile = TSDF_TILE;
 constexpr int kListBuckets = 64;
 constexpr int kBucketStride = 256;                          // bytes between buckets
 constexpr int kCounterBytes = kListBuckets * kBucketStride;
-static_assert(kTile == 8 || kTile == 16, "one wavefront per tile: 64 lanes x 1 or 4 pixels");
 
 // On top of the tiles a 2-D sparse table gives the same two quantities for ANY rectangle of tiles in four loads:
 // level (i, j) holds, at (ty, tx), the combination over the 2^i x 2^j tiles starting there (min of the x's, max of
@@ -73,8 +72,10 @@ __device__ __forceinline__ int tile_levels(int n) { return 32 - __clz(n); }   //
 __device__ __forceinline__ size_t tile_table_elems(int tw, int th) { return (size_t)tile_levels(tw) * tile_levels(th) * tw * th; }
 
 // block = 64 x 4: one wavefront per tile, four tiles per workgroup; grid = (ceil(tiles / 4), frames)
+template <int kTile>
 __global__ __launch_bounds__(256) void depth_tile_summary_per_tile(TileSummaryParams tp)
 {
+    static_assert(kTile == 8 || kTile == 16, "one wavefront per tile: 64 lanes x 1 or 4 pixels");
     const int tile = blockIdx.x * 4 + threadIdx.y, f = blockIdx.y;
     if (tile >= tp.tiles_w * tp.tiles_h) return;
     const int ty = tile / tp.tiles_w, tx = tile - ty * tp.tiles_w;
@@ -114,16 +115,19 @@ __global__ __launch_bounds__(256) void depth_tile_summary_per_tile(TileSummaryPa
     }
 }
 
-// The same values from whole-row reads: one wavefront per STRIP of four horizontally adjacent 16 x 16 tiles (16 rows x 64
-// pixels): a load instruction covers four rows of 256 contiguous bytes (16 lanes x 16 B per row) instead of sixteen 64-byte
-// row pieces, a lane accumulates its 4 rows x 4 pixels -- all in one tile -- and the 16 lanes of a tile combine by four
-// shuffles; min / max are exact and order-free, so the table is the one depth_tile_summary_per_tile builds (the claim
-// statistics of S-surf are identical).  The two table kernels were 72 us of a 32-frame launch -- a quarter of a 200^3 one.
-// block = 64 x 4 (four strips per workgroup); grid = (ceil(strips / 4), frames).
+// The same values from whole-row reads: one wavefront per STRIP of 64 pixels x kTile rows -- four 16-pixel tiles or eight
+// 8-pixel ones: a load instruction covers four rows of 256 contiguous bytes (16 lanes x 16 B per row) instead of 64-byte (or
+// 32-byte) row pieces, a lane accumulates its rows x 4 pixels -- all in one tile -- and the lanes of a tile combine by shuffles;
+// min / max are exact and order-free, so the table is the one depth_tile_summary_per_tile builds (tsdf_selftest_tile_tables
+// compares them; the claim statistics of S-surf are identical).  The two table kernels were 72 us of a 32-frame launch -- a
+// quarter of a 200^3 one.  block = 64 x 4 (four strips per workgroup); grid = (ceil(strips / 4), frames).
+template <int kTile>
 __global__ __launch_bounds__(256) void depth_tile_summary(TileSummaryParams tp)
 {
-    // (written for kTile == 16: the host launches depth_tile_summary_per_tile for any other tile size)
-    const int strips_w = (tp.tiles_w + 3) / 4;
+    static_assert(kTile == 8 || kTile == 16, "64-pixel strips of 16- or 8-pixel tiles");
+    constexpr int kTilesPerStrip = 64 / kTile;      // 4 or 8
+    constexpr int kLanesPerTileRow = kTile / 4;     // lanes (of 4 pixels) side by side in a tile: 4 or 2
+    const int strips_w = (tp.tiles_w + kTilesPerStrip - 1) / kTilesPerStrip;
     const int strip = blockIdx.x * 4 + threadIdx.y, f = blockIdx.y;
     if (strip >= strips_w * tp.tiles_h) return;
     const int ty = strip / strips_w, sx = strip - ty * strips_w;
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(256) void depth_tile_summary(TileSummaryParams tp)
     const bool vec = (tp.W & 3) == 0 && (reinterpret_cast<uintptr_t>(d) & 15) == 0 &&
                      (m == nullptr || (reinterpret_cast<uintptr_t>(m) & 3) == 0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < kTile / 4; ++i) {
         const int py = ty * kTile + rr + 4 * i;
         if (py >= tp.H || px0 >= tp.W) continue;
         float v[4];
@@ -169,16 +173,17 @@ __global__ __launch_bounds__(256) void depth_tile_summary(TileSummaryParams tp)
             if (valid) { mn = fminf(mn, v[j]); mx = fmaxf(mx, v[j]); }
         }
     }
-    // the 16 lanes of a tile: c4 in [4k, 4k + 3] (lane bits 0, 1) x the four row groups (lane bits 4, 5)
+    // the lanes of a tile: kLanesPerTileRow neighbours along the row (lane bits 0 [, 1]) x the four row groups (lane bits 4, 5)
     mn = fminf(mn, __shfl_xor(mn, 1));  mx = fmaxf(mx, __shfl_xor(mx, 1));
-    mn = fminf(mn, __shfl_xor(mn, 2));  mx = fmaxf(mx, __shfl_xor(mx, 2));
+    if constexpr (kLanesPerTileRow == 4) { mn = fminf(mn, __shfl_xor(mn, 2));  mx = fmaxf(mx, __shfl_xor(mx, 2)); }
     mn = fminf(mn, __shfl_xor(mn, 16)); mx = fmaxf(mx, __shfl_xor(mx, 16));
     mn = fminf(mn, __shfl_xor(mn, 32)); mx = fmaxf(mx, __shfl_xor(mx, 32));
     const unsigned long long bad = __ballot(!all_valid), nans = __ballot(nan);
-    if ((lane & 3) == 0 && rr == 0) {
-        const int k = c4 >> 2, tx = sx * 4 + k;
+    if ((lane & (kLanesPerTileRow - 1)) == 0 && rr == 0) {
+        const int k = c4 / kLanesPerTileRow, tx = sx * kTilesPerStrip + k;
         if (tx < tp.tiles_w) {
-            const unsigned long long tile_lanes = 0x000F000F000F000Full << (4 * k);
+            const unsigned long long row_lanes = kLanesPerTileRow == 4 ? 0x000F000F000F000Full : 0x0003000300030003ull;
+            const unsigned long long tile_lanes = row_lanes << (kLanesPerTileRow * k);
             const bool every_valid = (bad & tile_lanes) == 0ull, any_nan = (nans & tile_lanes) != 0ull;
             float2 out;
             out.x = (every_valid && !any_nan) ? mn : -inf;
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(256) void depth_tile_summary(TileSummaryParams tp)
 // from 2^i rows of it.  6 x n workgroups with one barrier each instead of one workgroup per frame walking through 29
 // dependent passes (55 us per launch: a third of a one-frame launch on a 200^3 volume).  Tables of more than
 // kTileLdsEntries tiles fall back to reading level (0, j) from memory after the barrier (same values).
-constexpr int kTileLdsEntries = kTile == 8 ? 5120 : 2048;   // float2: 2 x 40 KiB of LDS (a 640 x 480 frame has 4800 8-pixel tiles)
+constexpr int kTileLdsEntries = 5120;   // float2: 2 x 40 KiB of LDS (a 640 x 480 frame has 1200 16-pixel or 4800 8-pixel tiles)
 
 __global__ __launch_bounds__(256) void tile_sparse_table_scan(float2 *tables, int tw, int th)
 {
@@ -396,8 +401,8 @@ __device__ __forceinline__ int classify_patch(const IntegrateParams &p, const Cl
     const float wmax = (float)(p.W - 1), hmax = (float)(p.H - 1);
     if (!(u1 >= 0.0f) | !(v1 >= 0.0f) | !(u0 <= wmax) | !(v0 <= hmax)) return 2;   // the box misses the image
     const bool inside = (u0 >= 0.0f) & (v0 >= 0.0f) & (u1 <= wmax) & (v1 <= hmax);
-    const int tx0 = (int)(fmaxf(u0, 0.0f) * (1.0f / kTile)), tx1 = (int)(fminf(u1, wmax) * (1.0f / kTile));
-    const int ty0 = (int)(fmaxf(v0, 0.0f) * (1.0f / kTile)), ty1 = (int)(fminf(v1, hmax) * (1.0f / kTile));
+    const int tx0 = (int)(fmaxf(u0, 0.0f) * p.tile_inv), tx1 = (int)(fminf(u1, wmax) * p.tile_inv);     // tile_inv: a power of two, exact
+    const int ty0 = (int)(fmaxf(v0, 0.0f) * p.tile_inv), ty1 = (int)(fminf(v1, hmax) * p.tile_inv);
     // range query: four overlapping power-of-two blocks of level (ky, kx)
     const int kx = 31 - __clz(tx1 - tx0 + 1), ky = 31 - __clz(ty1 - ty0 + 1);
     const int n = p.tiles_w * p.tiles_h;
