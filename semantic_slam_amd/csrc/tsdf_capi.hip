@@ -497,7 +497,8 @@ int build_tile_tables(hipStream_t stream, const tsdf_config &c, const tsdfk::Int
             hipLaunchKernelGGL(tsdfk::depth_tile_summary<8>, dim3((unsigned)((strips + 3) / 4), m), dim3(64, 4), 0, stream, tp);
         }
         if (p.tiles_w * p.tiles_h <= tsdfk::kTileLdsEntries) {
-            hipLaunchKernelGGL(tsdfk::tile_sparse_table, dim3((unsigned)tile_levels_host(p.tiles_w), m), dim3(256), 0, stream, tp.tiles,
+            // (1024 threads when the frame has thousands of tiles: each of the kernel's ~12 barrier-separated passes visits every tile)
+            hipLaunchKernelGGL(tsdfk::tile_sparse_table, dim3((unsigned)tile_levels_host(p.tiles_w), m), dim3(p.tiles_w * p.tiles_h > 2048 ? 1024 : 256), 0, stream, tp.tiles,
                                p.tiles_w, p.tiles_h, k == 0 ? zero_me : (unsigned long long *)nullptr);
         } else {
             if (zero_me && k == 0) HIP_TRY(hipMemsetAsync(zero_me, 0, tsdfk::kCounterBytes, stream));
@@ -1796,7 +1797,7 @@ int tsdf_selftest_tile_tables(int32_t device, const float *depth_dev, const uint
         else
             hipLaunchKernelGGL(tsdfk::depth_tile_summary<8>, dim3((unsigned)((((tw + 7) / 8) * th + 3) / 4), 1), dim3(64, 4), 0, 0, tp);
         if (tw * th <= tsdfk::kTileLdsEntries)
-            hipLaunchKernelGGL(tsdfk::tile_sparse_table, dim3(lj, 1), dim3(256), 0, 0, d_a, tw, th, (unsigned long long *)nullptr);
+            hipLaunchKernelGGL(tsdfk::tile_sparse_table, dim3(lj, 1), dim3(tw * th > 2048 ? 1024 : 256), 0, 0, d_a, tw, th, (unsigned long long *)nullptr);
         else
             hipLaunchKernelGGL(tsdfk::tile_sparse_table_scan, dim3(lj, 1), dim3(256), 0, 0, d_a, tw, th);
         // b: one wavefront per tile, levels by scanning

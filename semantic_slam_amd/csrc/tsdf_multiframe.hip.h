@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void tile_sparse_table_scan(float2 *tables, in
 // workgroup per (x level j, frame): j + levels_y - 1 steps of two LDS reads per entry with a barrier each, instead of
 // 2^j + 2^i reads per entry.  zero_me (may be null): the launch's counter block (kCounterBytes: the sharded claim counters and
 // work-list lengths, see classify_brick_list), cleared here for the kernels that follow on the stream: saves a memset dispatch.
-__global__ __launch_bounds__(256) void tile_sparse_table(float2 *tables, int tw, int th, unsigned long long *zero_me)
+__global__ __launch_bounds__(1024) void tile_sparse_table(float2 *tables, int tw, int th, unsigned long long *zero_me)
 {
     if (zero_me != nullptr && blockIdx.x == 0 && blockIdx.y == 0)
         for (int k = threadIdx.x; k < kCounterBytes / 16; k += blockDim.x) reinterpret_cast<uint4 *>(zero_me)[k] = make_uint4(0u, 0u, 0u, 0u);
