@@ -447,10 +447,11 @@ bool tiles_fit(const tsdfk::IntegrateParams &p) { return (int64_t)p.tiles_w * p.
 
 // Pixels per depth tile edge for a slab: 8 where a fused launch is long enough to repay tables four times as large (the finer
 // tiles leave a fifth fewer wavefront-frames to the per-voxel path: tsdf_multiframe.hip.h), 16 otherwise and wherever the finer
-// grid of tiles would not fit the table kernels.  Measured on S-surf, ms per frame with 16 / 8: 128^3 0.0044 / 0.0051, 200^3
-// 0.0058 / 0.0064, 256^3 0.0076 / 0.0079, 320^3 0.0114 / 0.0111, 384^3 0.0164 / 0.0153, 512^3 0.0312 / 0.0275: the break-even
-// lies near 28 M voxels.  Members of a batch share one table layout and keep 16.
-constexpr int64_t kFineTileMinVoxels = 28000000;
+// grid of tiles would not fit the table kernels.  Measured on S-surf, ms per frame with 16 / 8: 128^3 0.0044 / 0.0051 (before
+// the table kernel ran 1024 threads), 200^3 0.00586 / 0.00586, 224^3 0.00642 / 0.00633, 256^3 0.00764 / 0.00741, 288^3 0.0097 /
+// 0.0093, 320^3 0.0114 / 0.0106, 512^3 0.0312 / 0.0270: the finer tiles pay from about 10 M voxels.  Members of a batch share one
+// table layout and keep 16.
+constexpr int64_t kFineTileMinVoxels = 10000000;
 thread_local bool g_create_for_batch = false;
 int tile_edge_for(const tsdf_config &c)
 {
