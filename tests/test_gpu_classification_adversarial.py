@@ -225,3 +225,45 @@ def test_unaligned_frame_buffers(cuda, oracle):
             t, w = vol.download()
         assert np.array_equal(w, ref_w) and np.array_equal(t.view(np.uint32), ref_t.view(np.uint32)), (d_off, m_off)
     assert stats[(1, 1)] == stats[(0, 0)] == stats[(3, 2)] and stats[(0, 0)][1] > 0 and stats[(0, 0)][2] > 0, stats
+
+
+@pytest.mark.parametrize("nz,tiles", [(40, "8-pixel tiles (10.5 M voxels)"), (36, "16-pixel tiles (9.4 M voxels)")])
+def test_single_pixels_at_the_edges_of_projected_boxes(cuda, oracle, nz, tiles):
+    """The pixel box of a brick's projected corners is widened by px_margin = 0.5625 + the projection error (csrc/tsdf_capi.hip):
+    exactly what it takes to hold the rounded pixel of every voxel of the brick.  A margin that is too small shows where ONE
+    pixel differs from its neighbours: the image is a far plane (every brick free space) with single pixels ("needles") whose
+    depth lies inside the volume, on a lattice of 37 x 29 pixels -- coprime with both tile sizes, so needles sit at every
+    position relative to the tiles -- and the camera moves in steps of 0.13 pixel, with a slight roll, so that needles
+    cross the edges of the projected boxes of all bricks along their rays.  A brick claimed "free" although one of its
+    voxels rounds onto a needle gets dist = 1 where the reference writes a band value.  Every voxel of the 512 x 512 x nz
+    slab against the reference's own kernel (whole_volume.py); both tile sizes (the library picks 8 from 10 M voxels)."""
+    import whole_volume as wv
+    if not wv.available():
+        pytest.skip("oracle/_ref/libtsdf_ref_hip.so not built")
+    dims, vs = (512, 512, nz), 0.002
+    origin = np.array([-0.512, -0.512, 1.0], np.float32)
+    cfg = capi.make_config(dims, vs, origin)
+    near = 1.0
+    px = near / float(synth.TUM_K[0])
+    depth0 = np.full((H, W), 3.0, np.float32)
+    needle = np.zeros((H, W), bool)
+    needle[3::29, 5::37] = True
+    frames = []
+    for k in range(24):
+        d = depth0.copy()
+        d[needle] = 1.0 + vs * (3 + (k * 7) % (nz - 6))          # inside the slab, another depth every frame
+        pose = synth.make_pose(synth.rot_z(0.002 * (k % 5)), [0.13 * k * px, -0.13 * (k % 9) * px, 0.0])
+        frames.append((pose, d))
+    dev = [cuda.from_numpy(d).cuda() for _, d in frames]
+    poses = np.stack([p for p, _ in frames])
+    ref_t, ref_w = wv.replay(cuda, f"needles{nz}", cfg.cam_K, dims, cfg.origin, cfg.voxel_size, cfg.trunc_margin, poses, dev)
+    band = int(((ref_t != 1.0) & (ref_w > 0)).sum())
+    assert band > 20000, f"the needles should leave band values behind ({band})"
+    for variant in (8, 0):
+        with capi.Volume(cfg) as vol:
+            vol.set_kernel_variant(variant)
+            vol.integrate_frames_device([d.data_ptr() for d in dev], poses)
+            info = vol.classification_info()
+            wv.assert_volume_equals_reference(cuda, f"needles, {tiles}, variant {variant}", vol, ref_t, ref_w, dims)
+        assert info[0] > 0.25, f"a good share of the wavefront-frames should have been claimed ({info[0]})"
+    wv.drop(f"needles{nz}")
