@@ -336,8 +336,8 @@ int tsdf_selftest_round(int32_t device, uint64_t *mismatches, float first_bad[4]
 /*
  * Device self-test of the depth tile tables the classified launches consult: builds the table of one frame (depth x mask,
  * mask_dev may be NULL) with the kernels the library launches (whole-row strips, levels by doubling) and with the plain
- * ones (one wavefront per tile, levels by scanning) and counts the entries that differ in any bit; *mismatches must come
- * back 0.
+ * ones (one wavefront per tile, levels by scanning), for both tile sizes the library uses (16 x 16 pixels; 8 x 8 for slabs of
+ * 10 M voxels and more), and counts the entries that differ in any bit; *mismatches must come back 0.
  */
 int tsdf_selftest_tile_tables(int32_t device, const float *depth_dev, const uint8_t *mask_dev, int32_t im_height,
                               int32_t im_width, float max_depth, uint64_t *mismatches);
