@@ -20,16 +20,18 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="ssurf")
 ap.add_argument("--grid", type=int, default=512)
 ap.add_argument("--shapes", default="16,4,1:8,8,1:4,8,2:4,4,4:2,4,8")
+ap.add_argument("--noise-mm", type=float, default=0.0)
+ap.add_argument("--holes", type=float, default=0.0)
 a = ap.parse_args()
 D = a.grid
 vs = {512: 0.005, 1024: 0.002}.get(D, 2.56 / D)
 dims = (D, D, D)
-W = bench.Workload(a.workload, dims, vs)
+W = bench.Workload(a.workload, dims, vs, a.noise_mm, a.holes)
 n = min(64, W.n_pose)
 poses = W.poses[:n]
 dev = [torch.from_numpy(np.ascontiguousarray(W.depths[i % len(W.depths)])).cuda() for i in range(n)]
 cfg = capi.make_config(dims, vs, W.origin, trunc=W.trunc, base2world=W.base2world)
-print(f"{a.workload} {D}^3 @ {vs * 1000:g} mm, {n} frames")
+print(f"{a.workload} {D}^3 @ {vs * 1000:g} mm, {n} frames" + (f", noise {a.noise_mm:g} mm, holes {a.holes:g}" if a.noise_mm or a.holes else ""))
 for shape in a.shapes.split(":"):
     q, r, s = (int(x) for x in shape.split(","))
     with capi.Volume(cfg) as vol:
