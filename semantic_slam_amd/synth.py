@@ -189,8 +189,8 @@ def sensor_imperfections(depths, noise_mm=0.0, holes=0.0, seed=1234):
             d = np.where(d > 0, d + rng.normal(0.0, noise_mm * 1e-3, d.shape).astype(np.float32), d)
             d = (np.round(d * 5000.0) / 5000.0).astype(np.float32)
         if holes > 0:
-            drop = rng.uniform(0, 1, (d.shape[0] // 8, d.shape[1] // 8)) < holes
-            d[np.kron(drop, np.ones((8, 8), bool))] = 0.0
+            drop = rng.uniform(0, 1, ((d.shape[0] + 7) // 8, (d.shape[1] + 7) // 8)) < holes      # (partial blocks at odd image sizes)
+            d[np.kron(drop, np.ones((8, 8), bool))[:d.shape[0], :d.shape[1]]] = 0.0
         out.append(np.ascontiguousarray(d, np.float32))
     return out
 
