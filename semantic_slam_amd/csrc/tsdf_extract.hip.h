@@ -15,12 +15,30 @@ namespace tsdfx {
 constexpr int kPerThread = 16;
 constexpr int kChunk = 256 * kPerThread;  // voxels per workgroup
 
-__device__ __forceinline__ bool is_surface(const float *tsdf, const float *weight, int64_t i,
-                                           int64_t n, float thr)
+__device__ __forceinline__ bool is_surface_value(float t, float w, float thr)
 {
     // ref: src/tsdf.cu:179 (tsdf_thresh is unused there too)
-    return i < n && fabsf(tsdf[i]) != 0.0f && weight[i] > thr;
+    return fabsf(t) != 0.0f && w > thr;
 }
+
+// The four voxels [i0, i0 + 4) of a lane: one 16-byte load per array where the quad lies inside the slab (i0 is a multiple
+// of four and the arrays are 16-byte aligned), single loads at the slab's ragged end.  Bit j of the result = voxel i0 + j is
+// a surface point.
+__device__ __forceinline__ uint32_t surface_quad(const float *tsdf, const float *weight, int64_t i0, int64_t n, float thr)
+{
+    if (i0 + 3 < n) {
+        const float4 t = *reinterpret_cast<const float4 *>(tsdf + i0);
+        const float4 w = *reinterpret_cast<const float4 *>(weight + i0);
+        return (is_surface_value(t.x, w.x, thr) ? 1u : 0u) | (is_surface_value(t.y, w.y, thr) ? 2u : 0u) |
+               (is_surface_value(t.z, w.z, thr) ? 4u : 0u) | (is_surface_value(t.w, w.w, thr) ? 8u : 0u);
+    }
+    uint32_t bits = 0u;
+    for (int j = 0; j < 4; ++j)
+        if (i0 + j < n && is_surface_value(tsdf[i0 + j], weight[i0 + j], thr)) bits |= 1u << j;
+    return bits;
+}
+
+constexpr int kQuadPasses = kChunk / 1024;   // passes of 256 lanes x 4 voxels over a workgroup's chunk
 
 __global__ __launch_bounds__(256) void surface_count(const float *tsdf, const float *weight,
                                                      int64_t n, float thr, uint32_t *counts)
@@ -29,10 +47,9 @@ __global__ __launch_bounds__(256) void surface_count(const float *tsdf, const fl
     const int64_t base = (int64_t)blockIdx.x * kChunk;
     uint32_t c = 0;
 #pragma unroll
-    for (int k = 0; k < kPerThread; ++k) {
-        bool f = is_surface(tsdf, weight, base + k * 256 + threadIdx.x, n, thr);
-        c += (uint32_t)__popcll(__ballot(f));
-    }
+    for (int k = 0; k < kQuadPasses; ++k)
+        c += (uint32_t)__popc(surface_quad(tsdf, weight, base + k * 1024 + (int64_t)threadIdx.x * 4, n, thr));
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
     if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = c;
     __syncthreads();
     if (threadIdx.x == 0) counts[blockIdx.x] = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
@@ -71,43 +88,54 @@ __global__ __launch_bounds__(256) void surface_emit(const float *tsdf, const flo
                                                     int dim_y, int z_begin, float ox, float oy,
                                                     float oz, float vs, float *xyz)
 {
-    __shared__ uint32_t cnt[kPerThread * 4];  // [k][wave] in output order
+    __shared__ uint32_t cnt[kQuadPasses * 4];  // [pass][wave] in output order
     const int64_t base = (int64_t)blockIdx.x * kChunk;
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
-    uint32_t flags = 0;
+    uint32_t flags = 0;                         // four bits per pass
 #pragma unroll
-    for (int k = 0; k < kPerThread; ++k) {
-        bool f = is_surface(tsdf, weight, base + k * 256 + threadIdx.x, n, thr);
-        unsigned long long b = __ballot(f);
-        flags |= (uint32_t)f << k;
-        if (lane == 0) cnt[k * 4 + wave] = (uint32_t)__popcll(b);
+    for (int k = 0; k < kQuadPasses; ++k) {
+        const uint32_t q = surface_quad(tsdf, weight, base + k * 1024 + (int64_t)threadIdx.x * 4, n, thr);
+        flags |= q << (4 * k);
+        uint32_t c = (uint32_t)__popc(q);
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+        if (lane == 0) cnt[k * 4 + wave] = c;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {  // 64-entry exclusive scan
+    if (threadIdx.x == 0) {  // exclusive scan in output order: pass, then wavefront (a wavefront's 256 voxels are consecutive)
         uint32_t run = 0;
-        for (int j = 0; j < kPerThread * 4; ++j) { uint32_t c = cnt[j]; cnt[j] = run; run += c; }
+        for (int j = 0; j < kQuadPasses * 4; ++j) { uint32_t c = cnt[j]; cnt[j] = run; run += c; }
     }
     __syncthreads();
-    if (flags == 0) return;
+    // (no lane leaves before the shuffle scans below: every lane of a wavefront takes part in them)
     const int64_t chunk_off = offsets[blockIdx.x];
     const int64_t slice = (int64_t)dim_x * dim_y;
-    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
-    for (int k = 0; k < kPerThread; ++k) {
-        bool f = (flags >> k) & 1u;
-        unsigned long long b = __ballot(f);
-        if (f) {
-            int64_t pos = chunk_off + cnt[k * 4 + wave] + __popcll(b & lt);
-            int64_t i = base + k * 256 + threadIdx.x;
-            int lz = (int)(i / slice);
-            int rem = (int)(i - (int64_t)lz * slice);
-            int y = rem / dim_x;
-            int x = rem - y * dim_x;
+    for (int k = 0; k < kQuadPasses; ++k) {
+        const uint32_t q = (flags >> (4 * k)) & 15u;
+        // points of the lanes below in this pass: an inclusive shuffle scan of the per-lane counts, minus the own
+        const uint32_t mine = (uint32_t)__popc(q);
+        uint32_t incl = mine;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off);
+            if (lane >= off) incl += up;
+        }
+        if (q == 0u) continue;
+        int64_t pos = chunk_off + cnt[k * 4 + wave] + (incl - mine);
+        const int64_t i0 = base + k * 1024 + (int64_t)threadIdx.x * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (!((q >> j) & 1u)) continue;
+            const int64_t i = i0 + j;
+            const int lz = (int)(i / slice);
+            const int rem = (int)(i - (int64_t)lz * slice);
+            const int y = rem / dim_x;
+            const int x = rem - y * dim_x;
             // ref: src/tsdf.cu:206-208
             xyz[3 * pos + 0] = ox + (float)x * vs;
             xyz[3 * pos + 1] = oy + (float)y * vs;
             xyz[3 * pos + 2] = oz + (float)(z_begin + lz) * vs;
+            ++pos;
         }
     }
 }
