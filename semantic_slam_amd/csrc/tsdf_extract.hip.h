@@ -55,30 +55,40 @@ __global__ __launch_bounds__(256) void surface_count(const float *tsdf, const fl
     if (threadIdx.x == 0) counts[blockIdx.x] = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
 }
 
-// Exclusive scan of the per-chunk counts by one 1024-thread workgroup (the list is short:
-// 32 Ki entries for a 512^3 grid).
+// Exclusive scan of the per-chunk counts by one 1024-thread workgroup (the list is short: 32 Ki entries for a 512^3 grid): per
+// tile of 1024 counts, a shuffle scan inside each wavefront, a shuffle scan of the sixteen wavefront totals, two barriers
+// (a Hillis-Steele scan over the whole tile took twenty: 61 us per call at 512^3).  A tile sums to <= 2^22.
 __global__ __launch_bounds__(1024) void scan_counts(const uint32_t *counts, int64_t n_chunks,
                                                     int64_t *offsets, int64_t *total)
 {
-    __shared__ uint32_t buf[1024];
-    __shared__ int64_t running;
-    if (threadIdx.x == 0) running = 0;
-    __syncthreads();
+    __shared__ uint32_t wave_total[16];
+    __shared__ uint32_t tile_total;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int64_t running = 0;                       // the same value in every thread
     for (int64_t base = 0; base < n_chunks; base += 1024) {
-        int64_t i = base + threadIdx.x;
-        uint32_t c = i < n_chunks ? counts[i] : 0u;
-        buf[threadIdx.x] = c;
-        __syncthreads();
-        for (int d = 1; d < 1024; d <<= 1) {  // inclusive Hillis-Steele; a tile sums to <= 2^22
-            uint32_t add = threadIdx.x >= (unsigned)d ? buf[threadIdx.x - d] : 0u;
-            __syncthreads();
-            buf[threadIdx.x] += add;
-            __syncthreads();
+        const int64_t i = base + threadIdx.x;
+        const uint32_t c = i < n_chunks ? counts[i] : 0u;
+        uint32_t incl = c;                     // inclusive scan inside the wavefront
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off);
+            if (lane >= off) incl += up;
         }
-        if (i < n_chunks) offsets[i] = running + (int64_t)(buf[threadIdx.x] - c);
+        if (lane == 63) wave_total[wave] = incl;
         __syncthreads();
-        if (threadIdx.x == 0) running += (int64_t)buf[1023];
+        if (wave == 0) {                       // exclusive scan of the sixteen totals, by the first wavefront
+            const uint32_t t = lane < 16 ? wave_total[lane] : 0u;
+            uint32_t ti = t;
+            for (int off = 1; off < 16; off <<= 1) {
+                const uint32_t up = __shfl_up(ti, off);
+                if (lane >= off) ti += up;
+            }
+            if (lane < 16) wave_total[lane] = ti - t;
+            if (lane == 15) tile_total = ti;
+        }
         __syncthreads();
+        if (i < n_chunks) offsets[i] = running + (int64_t)(wave_total[wave] + incl - c);
+        running += (int64_t)tile_total;
+        __syncthreads();                       // the totals are rewritten by the next tile
     }
     if (threadIdx.x == 0) *total = running;
 }
