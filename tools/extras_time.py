@@ -41,6 +41,10 @@ tg, xs = timeit(vol.extract_crossings)
 tc, ref = timeit(lambda: orc.zero_crossings(t, w, dims[:2], 0, D, vs, origin), 1)
 assert np.array_equal(xs, ref)
 print(f"zero-crossing vertices: {len(xs)} points  GPU {tg * 1e3:.1f} ms  CPU oracle {tc * 1e3:.0f} ms  x{tc / tg:.0f}")
+tg, tri = timeit(vol.extract_mesh)
+tc, ref = timeit(lambda: orc.mesh_triangles(t, w, dims[:2], 0, D, vs, origin), 1)
+assert np.array_equal(tri, ref)
+print(f"marching-tetrahedra mesh: {len(tri)} triangles  GPU {tg * 1e3:.1f} ms  CPU oracle {tc * 1e3:.0f} ms  x{tc / tg:.0f}")
 
 vol.labels_enable(0.5)
 rng = np.random.default_rng(0)
