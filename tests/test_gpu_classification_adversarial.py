@@ -267,3 +267,53 @@ def test_single_pixels_at_the_edges_of_projected_boxes(cuda, oracle, nz, tiles):
             wv.assert_volume_equals_reference(cuda, f"needles, {tiles}, variant {variant}", vol, ref_t, ref_w, dims)
         assert info[0] > 0.25, f"a good share of the wavefront-frames should have been claimed ({info[0]})"
     wv.drop(f"needles{nz}")
+
+
+@pytest.mark.parametrize("edge", ["left", "right", "top", "bottom"])
+def test_image_border_with_fine_tiles(cuda, oracle, edge):
+    """test_patches_touching_the_image_border on a slab large enough for 8-pixel depth tiles (512 x 512 x 40 voxels): one face
+    of the volume projects onto an image border, the camera slides in quarter-pixel steps so that the projected boxes of the
+    bricks along that face cross 0 / W - 1 / H - 1 and the +- px_margin band around them; alternately a far plane (free-space
+    claims need the box INSIDE the image) and a near plane (skip claims), with a column / row of invalid pixels hugging the
+    border every third frame.  Every voxel against the reference's own kernel."""
+    import whole_volume as wv
+    if not wv.available():
+        pytest.skip("oracle/_ref/libtsdf_ref_hip.so not built")
+    dims, vs = (512, 512, 40), 0.002
+    origin = np.array([-0.512, -0.512, 1.0], np.float32)
+    near, far = 1.0, 1.0 + dims[2] * vs
+    fx, fy = 535.4, 539.2
+    x0, x1 = float(origin[0]), float(origin[0]) + dims[0] * vs
+    y0, y1 = float(origin[1]), float(origin[1]) + dims[1] * vs
+    K = np.array(synth.TUM_K, np.float32)
+    if edge == "left":
+        K[2] = -fx * x0 / near
+    elif edge == "right":
+        K[2] = (W - 1) - fx * x1 / near
+    elif edge == "top":
+        K[5] = -fy * y0 / near
+    else:
+        K[5] = (H - 1) - fy * y1 / near
+    cfg = capi.make_config(dims, vs, origin, K=K)
+    px = near / fx
+    poses, depths = [], []
+    for k in range(-10, 11):
+        shift = [0.25 * k * px, 0.0, 0.0] if edge in ("left", "right") else [0.0, 0.25 * k * px, 0.0]
+        d = np.full((H, W), far + 0.5 if k % 2 == 0 else near - 0.2, np.float32)
+        if k % 3 == 0:                     # invalid pixels along the border the volume touches
+            if edge == "left": d[:, :2] = 0.0
+            elif edge == "right": d[:, -2:] = 0.0
+            elif edge == "top": d[:2, :] = 0.0
+            else: d[-2:, :] = 0.0
+        poses.append(synth.make_pose(np.eye(3), shift))
+        depths.append(d)
+    poses = np.stack(poses)
+    dev = [cuda.from_numpy(d).cuda() for d in depths]
+    ref_t, ref_w = wv.replay(cuda, f"border_{edge}", cfg.cam_K, dims, cfg.origin, cfg.voxel_size, cfg.trunc_margin, poses, dev)
+    assert 0 < float((ref_w > 0).sum()) < ref_w.numel(), "the border should cut the volume"
+    for variant in (8, 0):
+        with capi.Volume(cfg) as vol:
+            vol.set_kernel_variant(variant)
+            vol.integrate_frames_device([d.data_ptr() for d in dev], poses)
+            wv.assert_volume_equals_reference(cuda, f"image border {edge}, 8-pixel tiles, variant {variant}", vol, ref_t, ref_w, dims)
+    wv.drop(f"border_{edge}")
