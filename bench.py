@@ -57,10 +57,11 @@ def parse():
                     help="frame: one launch per step (default for sband / sfull); fused: up to 32 frames per pass over "
                          "the volume through tsdf_integrate_frames_device (default for ssurf / traj)")
     ap.add_argument("--variant", type=int, default=-1, help="force a kernel variant (DESIGN.md; overrides --mode)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="N > 1: weak = every rank integrates a slab as large as the whole N = 1 grid (the global grid "
-                         "grows with N: 512^3 -> 512x512x1024 -> 512x1024x1024 -> 1024^3 at N = 1, 2, 4, 8, same physical "
-                         "extent, finer voxels); strong = the N = 1 grid cut into N slabs")
+    ap.add_argument("--scaling", default="", choices=["", "weak", "strong"],
+                    help="N > 1 (default strong): strong = ONE global grid cut into N z-slabs -- by default BASELINE.json configs[3], "
+                         "1024^3 @ 2 mm (at N = 8 a rank's slab holds the 134 M voxels of the N = 1 grid); --grid names another grid "
+                         "to cut.  weak = every rank integrates a slab as large as the whole --grid (default 512^3) grid: the global "
+                         "grid grows with N inside the same physical box (512x512x1024 @ 5 / 5 / 2.5 mm, 512x1024x1024, 1024^3 @ 2.5 mm)")
     ap.add_argument("--dist-world1", action="store_true",
                     help="with one rank: still create the process group and run the N > 1 code path (barriers, all-reduces, halo step, "
                          "multi_gpu object) -- the RCCL rehearsal a one-GPU box allows (tests/test_gpu_bench_cli.py)")
@@ -83,10 +84,13 @@ def parse():
     ap.add_argument("--tum-dir", default="", help="traj: directory of the TUM fr3_office sequence (holding depth/<stamp>.png as "
                     "result/rgbd/associations.txt names them); when it exists the keyframes' real 16-bit depth frames are integrated "
                     "(value / 5000 m) instead of the rendered ones.  No dataset ships with the repository and none is fetched.")
+    ap.add_argument("--strong-leg", action="store_true",
+                    help="N > 1 (or --dist-world1): run the strong_512 / n1_same_job legs even with --no-extras (tests)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--depth-cache", default="", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
     a = ap.parse_args()
+    a.grid_given = bool(a.grid)
     if not a.grid:
         a.grid = 1024 if a.workload == "traj" else 512
     if not a.mode:
@@ -169,15 +173,26 @@ class Workload:
         return self.poses[idx], idx
 
 
+def default_voxel(D):
+    return {512: 0.005, 1024: 0.002}.get(D, 2.56 / D)
+
+
 def grid_for(args, world):
-    """Global dims and voxel size; weak scaling grows the grid with N inside the same physical box."""
+    """Global dims, voxel size, the number of slabs the grid is cut into and the scaling label of the line.
+
+    N = 1: BASELINE.json configs[1], 512^3 @ 5 mm.  N > 1, default ("strong"): ONE grid cut into N z-slabs -- BASELINE.json
+    configs[3], 1024^3 @ 2 mm, unless --grid names another grid to cut.  "weak": per-rank work fixed at the --grid grid,
+    the global grid grows with N inside the same physical box."""
+    part_world = args.emulate_world if (args.emulate_world > 1 and world == 1) else world
+    scaling = args.scaling or ("strong" if part_world > 1 else "weak")     # at N = 1 the label says nothing; "weak" as before
     D = args.grid
-    vs = {512: 0.005, 1024: 0.002}.get(D, 2.56 / D)
+    if part_world > 1 and scaling == "strong" and not args.grid_given and args.workload != "traj":
+        D = 1024                                   # configs[3]
+    vs = default_voxel(D)
     if args.voxel_mm > 0:
         vs = args.voxel_mm / 1000.0
     dims = [D, D, D]
-    part_world = args.emulate_world if (args.emulate_world > 1 and world == 1) else world
-    if args.scaling == "weak" and part_world > 1:
+    if scaling == "weak" and part_world > 1:
         # per-rank work fixed: z, then y, then x doubled in turn, voxels halved whenever z is doubled; a rank count that
         # is not a power of two just gets N x the slices
         k, n = 0, part_world
@@ -191,7 +206,11 @@ def grid_for(args, world):
         else:
             dims[2] *= part_world
             vs = vs / part_world
-    return tuple(dims), vs, part_world
+    return tuple(dims), vs, part_world, scaling
+
+
+def grid_label(dims):
+    return f"{dims[0]}³" if dims[0] == dims[1] == dims[2] else f"{dims[0]}×{dims[1]}×{dims[2]}"
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -294,6 +313,8 @@ def _pmc_pass(counters, kernel_substr, child_args, keep, timeout=150):
             return None, _PMC_BROKEN
         out = {}
         rows = [r for r in csv.DictReader(open(files[0])) if kernel_substr in r["Kernel_Name"]]
+        if rows:
+            out["kernel_name"] = rows[-1]["Kernel_Name"]      # as the profiler prints it: the name profiles/*_kernel_stats.csv carries
         for c in counters:
             v = [float(r["Counter_Value"]) for r in sorted((r for r in rows if r["Counter_Name"] == c), key=lambda r: int(r["Dispatch_Id"]))]
             v = v[-keep:]                # without the child's warm-up launches (they also settle the per-launch decisions)
@@ -341,6 +362,7 @@ def measure_traffic(kernel_substr, child_args, fpl=1, wide_reads=True):
         if r is None:
             return None, why
         vals[counter] = r[counter]
+        PMC_KERNEL_NAMES[kernel_substr] = r["kernel_name"]
     scale = 1.0 if fpl == 1 else vals["FETCH_SIZE"][1] * fpl / float(steps)      # dispatches -> launches of fpl frames
     fetch, write = 2.0 * vals["FETCH_SIZE"][0] * 1024.0 * scale, vals["WRITE_SIZE"][0] * 1024.0 * scale
     note = (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes over a short child run of "
@@ -354,31 +376,42 @@ def measure_traffic(kernel_substr, child_args, fpl=1, wide_reads=True):
     return fetch + write, note
 
 
-VALU_CYCLES_PER_INST = 3.55    # issue cycles per VALU wave-instruction of the per-voxel kernel's mix (tools/microbench/valu_rate.hip prices
-                               # its 159 VALU instructions per wavefront-frame at 565 cycles: DESIGN.md section 4)
+PMC_KERNEL_NAMES = {}          # kernel substring -> the kernel's full name as the profiled child runs saw it
+
+N_SIMDS = 1024                 # 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
 
 
 def measure_valu(kernel_substr, child_args, fpl=32):
-    """What an issue-bound launch is measured against: VALU wave-instructions issued per SIMD, priced at the measured issue cost
-    of this kernel's instruction mix, over the launch's cycles (GRBM_GUI_ACTIVE summed over the 8 XCDs; 1024 SIMDs)."""
-    r, why = _pmc_pass(["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVES", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"], kernel_substr, child_args,
-                       _child_shape(child_args, fpl)[0])
+    """What an issue-bound launch is measured against, from counters alone (no modelled instruction price): the share of
+    the launch's SIMD-cycles in which a VALU instruction was executing -- SQ_ACTIVE_INST_VALU counts, per wavefront, the
+    quad-cycles it spends in VALU instructions (MI355X_MICROARCH.md, "s_memtime tick vs SQ PMC units"; a SIMD executes one
+    wavefront's VALU instruction at a time, so the sum over a SIMD's wavefronts cannot exceed its cycles) -- over
+    GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs: rocprofv3's own VALUBusy formula.  The scalar unit likewise (SQ_ACTIVE_INST_SCA,
+    one unit per CU)."""
+    r, why = _pmc_pass(["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA",
+                        "SQ_WAIT_ANY", "GRBM_GUI_ACTIVE"], kernel_substr, child_args, _child_shape(child_args, fpl)[0])
     if r is None:
         return None, why
+    PMC_KERNEL_NAMES[kernel_substr] = r["kernel_name"]
     cyc = r["GRBM_GUI_ACTIVE"][0] / 8.0
     if cyc <= 0:
         return None, "GRBM_GUI_ACTIVE read 0"
     steps = _child_shape(child_args, fpl)[1]
     per = r["SQ_INSTS_VALU"][1] * fpl / float(steps) if fpl > 1 else 1.0      # dispatches -> launches of fpl frames
-    return {"valu_issue_frac": round(r["SQ_INSTS_VALU"][0] * VALU_CYCLES_PER_INST / (cyc * 1024.0), 4),
+    valu_cyc = r["SQ_ACTIVE_INST_VALU"][0] * 4.0
+    return {"valu_issue_frac": round(valu_cyc / (cyc * N_SIMDS), 4),
+            "salu_busy_frac": round(r["SQ_ACTIVE_INST_SCA"][0] * 4.0 / (cyc * N_SIMDS / 4.0), 4),
+            "cycles_per_valu_inst": round(valu_cyc / max(r["SQ_INSTS_VALU"][0], 1.0), 3),
             "valu_insts_per_launch": int(r["SQ_INSTS_VALU"][0] * per), "salu_insts_per_launch": int(r["SQ_INSTS_SALU"][0] * per),
             "waves_per_launch": int(r["SQ_WAVES"][0] * per), "kernel_cycles": int(cyc * per),
-            "mean_waves_per_simd": round(r["SQ_WAVE_CYCLES"][0] * 4.0 / (cyc * 1024.0), 2),
-            "cycles_per_valu_inst_assumed": VALU_CYCLES_PER_INST,
+            "mean_waves_per_simd": round(r["SQ_WAVE_CYCLES"][0] * 4.0 / (cyc * N_SIMDS), 2),
+            "wait_any_frac_of_wave_cycles": round(r["SQ_WAIT_ANY"][0] / max(r["SQ_WAVE_CYCLES"][0], 1.0), 4),
+            "source": "bench.py measure_valu: rocprofv3 --pmc counters only (no modelled constant)",
             "note": "one rocprofv3 --pmc pass over a short child run, means over "
                     f"{r['SQ_INSTS_VALU'][1]} dispatches ({steps} consecutive frames; per-launch figures scaled to {fpl} frames): "
-                    "valu_issue_frac = SQ_INSTS_VALU (wave instructions) x the measured issue cost of "
-                    "this instruction mix / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); 1.0 = the VALUs issue back to back"}, None
+                    "valu_issue_frac = SQ_ACTIVE_INST_VALU x 4 (quad-cycles -> cycles in which a wavefront's VALU instruction "
+                    "executes) / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), measured, <= 1 by construction; cycles_per_valu_inst = the same "
+                    "cycles / SQ_INSTS_VALU (wave instructions); salu_busy_frac = SQ_ACTIVE_INST_SCA x 4 / (cycles x 256 scalar units)"}, None
 
 
 def main():
@@ -417,7 +450,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     comm_dev = "cpu" if backend == "gloo" else "cuda"
 
-    dims, vs, part_world = grid_for(args, world)
+    dims, vs, part_world, scaling = grid_for(args, world)
     cache_dir = args.depth_cache
     own_cache = None
     if not cache_dir and not args.no_traffic and not args.pmc_child and world == 1:
@@ -440,12 +473,13 @@ def main():
     d_dev = [torch.from_numpy(d).cuda() for d in W.depths]
     H, Wd = W.depths[0].shape
 
-    def run_block(v, start, n):
+    def run_block(v, start, n, Wl=None, ddev=None):
         """n consecutive steps queued back to back on the handle's stream; device milliseconds (HIP events there)."""
-        poses, idx = W.block(start, n)
-        if len(d_dev) == 1:
-            return v.integrate_sequence_timed(d_dev[0].data_ptr(), poses)
-        return v.integrate_frames_timed([d_dev[i].data_ptr() for i in idx], poses)
+        Wl, ddev = Wl or W, ddev or d_dev
+        poses, idx = Wl.block(start, n)
+        if len(ddev) == 1:
+            return v.integrate_sequence_timed(ddev[0].data_ptr(), poses)
+        return v.integrate_frames_timed([ddev[i].data_ptr() for i in idx], poses)
 
     def fence():
         torch.cuda.synchronize()
@@ -460,51 +494,58 @@ def main():
         vol.close()
         return
 
-    # ---- warm-up: at least W steps, at least two full launches, at least 8 steps -------------------------------
+    on_dev = "cpu" if backend == "gloo" else "cuda"
+
+    def timed_region(v, K, Wl=None, ddev=None, min_ms=MIN_TIMED_MS):
+        """The contract's timed region on handle v: warm-up (at least --warmup steps, two full launches, 8 steps), a calibration
+        block, then the K-step sequence `repeats` times between barrier + synchronize fences.  Returns (wall seconds and kernel
+        milliseconds, both max over ranks; steps timed; repeats; frames integrated into v so far; warm-up steps)."""
+        Wl, ddev = Wl or W, ddev or d_dev
+        fpl_ = v.frames_per_launch
+        n_warm = max(args.warmup, 2 * fpl_, 8)
+        run_block(v, 0, n_warm, Wl, ddev)
+        cal_ms = run_block(v, n_warm, K, Wl, ddev)     # calibration block (also warm): how long K steps take
+        done = n_warm + K
+        repeats = max(1, int(math.ceil(1.2 * min_ms / max(cal_ms, 1e-3))))   # 20 % margin: the calibration block may run slow
+        if dist is not None:   # every rank times the same number of blocks
+            rt = torch.tensor([repeats], dtype=torch.int64, device=on_dev)
+            dist.all_reduce(rt, op=dist.ReduceOp.MAX)
+            repeats = int(rt[0])
+        # one call: the repeats' launches are queued back to back on the handle's stream (a call per repeat left the device
+        # idle for ~0.4 ms between repeats while the host drained, returned and came back: 5 % at --steps 20); with a depth frame
+        # per pose the call's arguments (K x repeats device pointers and poses) are marshalled ahead of the timed region
+        timed_call = None
+        if len(ddev) > 1:
+            poses_t, idx_t = Wl.block(done, K * repeats)
+            timed_call = v.frames_timed_call([ddev[i].data_ptr() for i in idx_t], poses_t)
+        fence()
+        t0 = time.perf_counter()
+        k_ms = timed_call() if timed_call is not None else run_block(v, done, K * repeats, Wl, ddev)
+        fence()
+        wall_ = time.perf_counter() - t0
+        tt = torch.tensor([wall_, k_ms], dtype=torch.float64, device=on_dev)
+        if dist is not None:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt[0]), float(tt[1]), K * repeats, repeats, done + K * repeats, n_warm
+
+    def check_full_coverage(v, Wl, done, what):
+        """The promise of the S-band / S-full workloads, asserted on the device's result: every voxel of the slab updated by
+        every frame (and, S-band, every TSDF value inside the truncation band).  Returns (updates per frame, slab voxels)."""
+        t_h, w_h = v.download()
+        upd = float(w_h.astype(np.float64).sum())       # each update adds exactly 1 to one weight
+        if Wl.full_coverage:
+            assert w_h.min() == w_h.max() == float(done), f"{what}: full coverage means every voxel every frame"
+            if Wl.name == "sfull":
+                assert np.all(t_h == 1.0)
+            else:
+                assert 0.0 < t_h.min() and t_h.max() < 1.0, f"{what}: S-band keeps every TSDF value inside the truncation band"
+        return upd / done, v.n_voxels
+
     K = args.steps
-    n_warm = max(args.warmup, 2 * fpl, 8)
-    run_block(vol, 0, n_warm)
-    cal_ms = run_block(vol, n_warm, K)                 # calibration block (also warm): how long K steps take
-    frames_done = n_warm + K
-    repeats = max(1, int(math.ceil(1.2 * MIN_TIMED_MS / max(cal_ms, 1e-3))))   # 20 % margin: the calibration block may run slow
-    if dist is not None:   # every rank times the same number of blocks
-        rt = torch.tensor([repeats], dtype=torch.int64, device="cpu" if backend == "gloo" else "cuda")
-        dist.all_reduce(rt, op=dist.ReduceOp.MAX)
-        repeats = int(rt[0])
-
-    # ---- timed region: the K-step sequence, `repeats` times ------------------------------------------------------
-    # one call: the repeats' launches are queued back to back on the handle's stream (a call per repeat left the device
-    # idle for ~0.4 ms between repeats while the host drained, returned and came back: 5 % at --steps 20); with a depth frame
-    # per pose the call's arguments (K x repeats device pointers and poses) are marshalled ahead of the timed region
-    timed_call = None
-    if len(d_dev) > 1:
-        poses_t, idx_t = W.block(frames_done, K * repeats)
-        timed_call = vol.frames_timed_call([d_dev[i].data_ptr() for i in idx_t], poses_t)
-    fence()
-    t0 = time.perf_counter()
-    kernel_ms_total = timed_call() if timed_call is not None else run_block(vol, frames_done, K * repeats)
-    fence()
-    wall = time.perf_counter() - t0
-    timed_steps = K * repeats
-    frames_done += timed_steps
-
-    tt = torch.tensor([wall, kernel_ms_total], dtype=torch.float64, device="cpu" if backend == "gloo" else "cuda")
-    if dist is not None:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    wall, kernel_ms_total = float(tt[0]), float(tt[1])
+    wall, kernel_ms_total, timed_steps, repeats, frames_done, n_warm = timed_region(vol, K)
 
     # ---- what was integrated: count updates on this rank's slab ------------------------------------------------
-    t_host, w_host = vol.download()
-    n_slab = vol.n_voxels
-    upd_total = float(w_host.astype(np.float64).sum())  # each update adds exactly 1 to one weight
-    if W.full_coverage:
-        assert w_host.min() == w_host.max() == float(frames_done), "full coverage: every voxel every frame"
-        if args.workload == "sfull":
-            assert np.all(t_host == 1.0)
-        else:
-            assert 0.0 < t_host.min() and t_host.max() < 1.0, "S-band: every TSDF value inside the truncation band"
-    n_upd_per_frame = upd_total / frames_done
-    del t_host, w_host
+    n_upd_per_frame, n_slab = check_full_coverage(vol, W, frames_done, "headline")
     # several frames per pass over a scene with free / unseen space: what a launch touches (its voxels updated by at least one
     # of its frames) is counted, not bounded -- every launch of one pass over the step sequence on a fresh volume, weights > 0
     # counted on the device; per fpl frames, like the measured traffic it is compared with
@@ -522,6 +563,53 @@ def main():
             total += int(torch.count_nonzero(w_dev))
         touched_per_launch = total * fpl / float(seq)
         del t_dev, w_dev
+
+    # ---- N > 1: north_star's "512^3 grid at 1, 2, 4 and 8 GPUs" beside the headline, and the N = 1 figure both scale from ---
+    strong_512 = n1_here = None
+    frame_bytes_ = 4.0 * H * Wd + 100.0
+    if multi and (args.strong_leg or not args.no_extras) and args.workload == "sband" and args.variant < 0 and args.emulate_world <= 1:
+        sd, svs = (512, 512, 512), 0.005
+        Ws = Workload("sband", sd, svs)
+        s_dev = [torch.from_numpy(Ws.depths[0]).cuda()]
+        szb, sze = rank * sd[2] // world, (rank + 1) * sd[2] // world
+        with capi.Volume(capi.make_config(sd, svs, Ws.origin, trunc=Ws.trunc, z_begin=szb, z_end=sze, device=local_rank)) as sv_:
+            sv_.set_kernel_variant(3)
+            s_wall, s_kms, s_steps, s_rep, s_done, _ = timed_region(sv_, K, Ws, s_dev, min_ms=150.0)
+            check_full_coverage(sv_, Ws, s_done, "strong_512")
+            slab_bytes = 8 * sv_.n_voxels
+        n_s = sd[0] * sd[1] * sd[2]
+        s_ms = s_wall / s_steps * 1e3
+        strong_512 = {
+            "workload": f"sband 512x512x512 @ 5 mm cut into {world} z-slab(s) of {sze - szb} slices, one launch per step per rank "
+                        "(BASELINE.json north_star: \"a 512^3 grid at 1, 2, 4 and 8 GPUs\"; strong scaling)",
+            "grid": list(sd), "voxel_size_m": svs, "n_gpus": world, "scaling": "strong",
+            "ms_per_step": round(s_ms, 5), "value": round(n_s / s_ms / 1e3, 1), "unit": "Mvoxels/s", "steps_timed": s_steps,
+            "hbm_GBps_all_ranks": round((16.0 * n_s + world * frame_bytes_) / (s_ms * 1e-3) / 1e9, 1),
+            "hbm_frac_of_n_gpus": round((16.0 * n_s + world * frame_bytes_) / (s_ms * 1e-3) / 1e9 / (world * HBM_PEAK_GBS), 4),
+            "slab_resident_bytes": int(slab_bytes), "cache_resident": bool(slab_bytes < 256 * 2 ** 20),
+            "note": "same fences and max-over-ranks timing as the headline; cache_resident: a rank's slab (TSDF + weight) is smaller "
+                    "than the 256 MB Infinity Cache, so its 16 B per voxel need not all reach HBM -- hbm_frac_of_n_gpus is then the "
+                    "algorithmic rate against N x 8 TB/s, not an HBM measurement"}
+        del s_dev
+        if rank == 0:
+            # the N = 1 configuration (configs[1]: the whole 512^3 grid on one GPU) on THIS node's first GPU, while the other
+            # ranks wait at the next fence: the figure the N-GPU values scale from, measured in the same job
+            with capi.Volume(capi.make_config(sd, svs, Ws.origin, trunc=Ws.trunc, device=local_rank)) as nv:
+                nv.set_kernel_variant(3)
+                n_dev = [torch.from_numpy(Ws.depths[0]).cuda()]
+                run_block(nv, 0, 40, Ws, n_dev)
+                tot, st = 0.0, 0
+                t1 = time.perf_counter()
+                while tot < 150.0:
+                    tot += run_block(nv, 40 + st, 64, Ws, n_dev)
+                    st += 64
+                torch.cuda.synchronize()
+                n1_wall = (time.perf_counter() - t1) / st * 1e3
+                n1_here = {"workload": "sband 512x512x512 @ 5 mm on one GPU (rank 0 alone; BASELINE.json configs[1], the N = 1 line's workload)",
+                           "ms_per_step": round(n1_wall, 5), "kernel_ms": round(tot / st, 5), "value": round(n_s / n1_wall / 1e3, 1),
+                           "unit": "Mvoxels/s", "hbm_frac": round((16.0 * n_s + frame_bytes_) / (tot / st * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                           "steps_timed": st}
+        fence()
 
     # ---- after the timed region, N > 1: the one-voxel halo (RCCL) and the extraction it feeds --------------------
     extraction = None
@@ -608,8 +696,8 @@ def main():
     kernel_ms = kernel_ms_total / launches
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
     if fpl == 1:
-        kname = ("tsdfk::integrate_tile<2, true, true, false, true, false, true, false, false>" if cfg.dim_x % 256 == 0 else
-                 "tsdfk::integrate_multi_single<true, true>") if variant in (0, 3) else f"variant {variant}"
+        kname = ("void tsdfk::integrate_tile<2, false>(tsdfk::IntegrateParams)" if cfg.dim_x % 256 == 0 else
+                 "tsdfk::integrate_multi_single<...>") if variant in (0, 3) else f"variant {variant}"
         ksub = "integrate_tile<" if cfg.dim_x % 256 == 0 else "integrate_multi_single<"
     else:
         # what the library launches for a known sequence: over the brick work list while the previous launch's claims pay
@@ -625,24 +713,38 @@ def main():
         traffic, traffic_note = measure_traffic(ksub, child_args_for(args, variant=variant, steps=6 if fpl == 1 else W.n_pose if W.n_pose >= 2 * fpl else 3 * fpl),
                                                 fpl=fpl, wide_reads="brick_list" not in ksub)
 
+    # the kernel's name as the profiler printed it in this run's child passes (what profiles/*_kernel_stats.csv lists); without
+    # such a pass (N > 1, --no-traffic) the name the source gives it
+    kname_source = "static (no profiled pass in this run)"
+    if ksub in PMC_KERNEL_NAMES:
+        kname, kname_source = PMC_KERNEL_NAMES[ksub], "rocprofv3 Kernel_Name of this run's PMC passes"
+
     mode_desc = ("one kernel launch per step (tsdf_integrate_device per frame: the reference's TSDF::Integrate call shape)" if fpl == 1
                  else f"tsdf_integrate_frames_device, up to {fpl} frames per pass over the volume")
     line = {
-        "metric": f"Mvoxels/sec integrated, {D}³ grid @ 640×480 depth; achieved HBM GB/s %peak",   # BASELINE.json
+        # BASELINE.json's metric, naming the grid that was integrated (N = 1: its 512³; N > 1: configs[3]'s 1024³ by default)
+        "metric": f"Mvoxels/sec integrated, {grid_label(dims)} grid @ 640×480 depth; achieved HBM GB/s %peak",
         "value": round((n_global if args.emulate_world <= 1 else n_slab) * timed_steps / wall / 1e6, 1),
         "unit": "Mvoxels/s",
         "n_gpus": world, "steps": K, "warmup": args.warmup,
         "ms_per_step": round(wall / timed_steps * 1e3, 5),
         "higher_is_better": True,
-        "scaling": args.scaling,
+        "scaling": scaling,
         "vs_baseline": None,            # the reference publishes no number for this metric
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"{args.workload} {dims[0]}x{dims[1]}x{dims[2]} @ {vs * 1000:g} mm, 640x480 depth resident in HBM: "
                                f"{W.desc}; {mode_desc}",
                    "grid": list(dims), "voxel_size_m": vs, "image": [H, Wd], "trunc_margin_m": float(cfg.trunc_margin),
-                   "partition": f"{world} z-slab(s) of {ze - zb} slices ({n_slab} voxels), one per GPU"
-                                + (f"; {args.scaling} scaling from the {D}^3 grid of N = 1" if world > 1 else ""),
+                   "partition": f"{part_world} z-slab(s) of {ze - zb} slices ({n_slab} voxels), one per GPU"
+                                + ("" if part_world == 1 else
+                                   f"; strong scaling: the {dims[0]}x{dims[1]}x{dims[2]} @ {vs * 1000:g} mm grid"
+                                   + (" of BASELINE.json configs[3]" if dims == (1024, 1024, 1024) and abs(vs - 0.002) < 1e-9 else "")
+                                   + f" is the same at every N > 1 (at N = 8 a slab holds the 134 M voxels of the N = 1 line's 512^3 grid)"
+                                   if scaling == "strong" else
+                                   f"; weak scaling: every rank's slab holds the {D}^3 voxels of the N = 1 grid, the global grid grows with N")
+                                + (f"; single-GPU rehearsal of rank {args.emulate_rank} of {part_world} (value = this slab's rate)"
+                                   if args.emulate_world > 1 and world == 1 else ""),
                    "mode": args.mode, "kernel_variant": variant, "frames_per_launch": fpl},
         "timing": {"timed_steps": timed_steps, "repeats": repeats, "timed_region_s": round(wall, 4),
                    "kernel_s": round(kernel_ms_total * 1e-3, 4), "warmup_steps_run": n_warm + K,
@@ -652,7 +754,7 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None if traffic is None else int(traffic),
                      "traffic_note": traffic_note,
                      "traffic_over_algorithmic": None if traffic is None else round(traffic / alg_bytes, 4),
-                     "kernel": kname, "launches": launches, "kernel_ms": round(kernel_ms, 5),
+                     "kernel": kname, "kernel_name_source": kname_source, "launches": launches, "kernel_ms": round(kernel_ms, 5),
                      "algorithmic_bytes_per_launch": int(alg_bytes),
                      "algorithmic_bytes_per_unit": 16, "units_per_launch": int(units_per_launch),
                      "unit_name": unit_name, "bytes_model": bytes_model,
@@ -661,10 +763,21 @@ def main():
                              "stream) / launches; achieved = algorithmic_bytes_per_launch / kernel_ms"},
     }
     if multi:
-        # what a SCALE record must show: how many ranks the communicator saw, through which backend, and what the halo costs
+        # what a SCALE record must show: how many ranks the communicator saw, through which backend, what the halo costs, and the
+        # job's rate against N GPUs' HBM (SURVEY.md section 8d "scaling table": Mvox/s and % of (G x 8 TB/s))
+        job_bytes = 16.0 * n_upd_per_frame * world + world * frame_bytes if fpl == 1 else None
         line["multi_gpu"] = {"world": world, "backend": "rccl (torch.distributed 'nccl')" if backend != "gloo" else "gloo",
                              "comm_device": comm_dev, "halo_bytes_per_boundary": 8 * dims[0] * dims[1],
-                             "data_path_collectives": 0, "halo_and_extraction_ran": extraction is not None and not extraction_failed}
+                             "data_path_collectives": 0, "halo_and_extraction_ran": extraction is not None and not extraction_failed,
+                             "global_grid": list(dims), "voxel_size_m": vs, "voxels_per_rank": int(n_slab),
+                             "hbm_GBps_all_ranks": None if job_bytes is None else round(job_bytes / (wall / timed_steps) / 1e9, 1),
+                             "hbm_frac_of_n_gpus": None if job_bytes is None else round(job_bytes / (wall / timed_steps) / 1e9 / (world * HBM_PEAK_GBS), 4),
+                             "hbm_note": "algorithmic bytes of all ranks (16 B x voxels updated per frame, this rank's count x N, + a depth frame "
+                                         "per rank) / ms_per_step (wall, max over ranks) against N x 8 TB/s"}
+        if strong_512 is not None:
+            line["strong_512"] = strong_512
+        if n1_here is not None:
+            line["n1_same_job"] = n1_here
     if extraction is not None:
         line["extraction"] = extraction
         line["extraction_hung"] = bool(extraction_hung)

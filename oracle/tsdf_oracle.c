@@ -12,12 +12,16 @@
  *
  * Pinning: the reference has no tests or golden vectors for this path.
  * The voxel update is pinned bit-for-bit against the reference's own kernel body
- * (src/tsdf.cu:15-60) compiled for the host from where it lies (oracle/_ref, built by
- * `make -C oracle ref` in the build container; tests/test_oracle_vs_ref.py) and against the
- * fixtures under tests/golden/ that were generated from that build
- * (tests/golden/make_golden.py).  The 4x4 helpers and the file writers are member
- * functions of a class whose header needs OpenCV + CUDA, so they cannot be built here:
- * they are pinned by known-answer tests only (tests/test_pose_math.py).
+ * (src/tsdf.cu:15-60): compiled by hipcc for gfx950 exactly as it stands and run on the device
+ * (`make -C oracle ref_hip`, tests/test_gpu_ref_kernel.py), compiled for the host from where it lies
+ * (`make -C oracle ref`, tests/test_oracle_vs_ref.py), and through the fixtures under tests/golden/ that
+ * were generated from that build (tests/golden/make_golden.py).  The 4x4 helpers and the .ply writer are
+ * pinned against the reference's own multiply_matrix / invert_matrix / SaveVoxelGrid2SurfacePointCloud
+ * (src/tsdf.cu:253-403, :170-218) compiled for the host as they stand (`make -C oracle ref_host`,
+ * tests/test_pose_math.py, tests/test_writers_and_adapters.py).  The constructor / Integrate glue and the
+ * .bin dump inside ~TSDF touch the class's fields (its header needs OpenCV + CUDA) and cannot be compiled:
+ * restated from the text, known-answer tests only.  The label, colour, crossing and mesh rules are not
+ * reference functions: parity unpinned, stated where each is defined.
  */
 #include <math.h>
 #include <stdint.h>
@@ -474,6 +478,11 @@ int64_t oracle_integrate_labels(const float *cam_K, const float *cam2base, const
                                 uint16_t *label, float *fp, float *bp)
 {
     int64_t n = 0;
+    /* rows (z, y) are independent (a voxel's label state depends on nothing but its own history): all host
+     * threads, so that a whole 2048 x 2048 x 256 slab of BASELINE configs[4] can be checked voxel by voxel */
+#ifdef _OPENMP
+#pragma omp parallel for collapse(2) schedule(static) reduction(+ : n)
+#endif
     for (int gz = z_begin; gz < z_end; ++gz)
         for (int gy = 0; gy < dim_y; ++gy)
             for (int gx = 0; gx < dim_x; ++gx) {
@@ -545,6 +554,11 @@ int64_t oracle_integrate_colour(const float *cam_K, const float *cam2base, const
                                 float max_depth, const float *weight, uint32_t *colour)
 {
     int64_t n = 0;
+    /* rows (z, y) are independent (a voxel's label state depends on nothing but its own history): all host
+     * threads, so that a whole 2048 x 2048 x 256 slab of BASELINE configs[4] can be checked voxel by voxel */
+#ifdef _OPENMP
+#pragma omp parallel for collapse(2) schedule(static) reduction(+ : n)
+#endif
     for (int gz = z_begin; gz < z_end; ++gz)
         for (int gy = 0; gy < dim_y; ++gy)
             for (int gx = 0; gx < dim_x; ++gx) {

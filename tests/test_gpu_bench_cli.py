@@ -56,17 +56,31 @@ def test_two_ranks_as_the_driver_launches_them(cuda):
     port = so.getsockname()[1]
     so.close()
     rc, lines, err = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", str(port), "bench.py", "--gpus", "2", "--grid", "256"] + QUICK, env={"TSDF_BENCH_BACKEND": "gloo"})
+                          "--master-port", str(port), "bench.py", "--gpus", "2", "--grid", "256", "--strong-leg"] + QUICK,
+                         env={"TSDF_BENCH_BACKEND": "gloo"})
     assert rc == 0, err
     assert len(lines) == 1, "rank 0 alone prints"
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
     m = d["multi_gpu"]
     assert m["world"] == 2 and m["backend"] == "gloo" and m["data_path_collectives"] == 0 and m["halo_and_extraction_ran"] is True
     assert m["halo_bytes_per_boundary"] == 8 * d["config"]["grid"][0] * d["config"]["grid"][1]
     assert d["extraction_hung"] is False and d["extraction"]["vertices"] >= 0 and "error" not in d["extraction"]
-    # weak scaling: the grid doubled along z, every rank owns what N = 1 owns
-    assert d["config"]["grid"] == [256, 256, 512] and "2 z-slab(s) of 256 slices" in d["config"]["partition"]
+    # strong scaling: the named grid itself cut in two; metric, workload and partition say what ran
+    assert d["config"]["grid"] == [256, 256, 256] and d["config"]["voxel_size_m"] == 0.01
+    assert "256³ grid" in d["metric"] and "256x256x256 @ 10 mm" in d["config"]["workload"]
+    assert "2 z-slab(s) of 128 slices" in d["config"]["partition"] and "strong scaling" in d["config"]["partition"]
+    assert m["global_grid"] == [256, 256, 256] and m["voxels_per_rank"] == 256 * 256 * 128
+    assert abs(d["value"] - 256 ** 3 / d["ms_per_step"] / 1e3) / d["value"] < 2e-3
+    assert 0.0 < m["hbm_frac_of_n_gpus"] <= 1.0
+    assert abs(m["hbm_frac_of_n_gpus"] - m["hbm_GBps_all_ranks"] / (2 * 8000.0)) < 1e-3
+    # north_star's 512^3 split beside it, and the N = 1 figure measured in the same job
+    s5 = d["strong_512"]
+    assert s5["grid"] == [512, 512, 512] and s5["voxel_size_m"] == 0.005 and s5["n_gpus"] == 2 and s5["scaling"] == "strong"
+    assert "2 z-slab(s) of 256 slices" in s5["workload"] and s5["cache_resident"] is False and s5["slab_resident_bytes"] == 8 * 512 * 512 * 256
+    assert abs(s5["value"] - 512 ** 3 / s5["ms_per_step"] / 1e3) / s5["value"] < 2e-3 and 0.0 < s5["hbm_frac_of_n_gpus"] <= 1.0
+    n1 = d["n1_same_job"]
+    assert "512x512x512 @ 5 mm" in n1["workload"] and n1["value"] > 0 and 0.3 < n1["hbm_frac"] <= 1.0
 
 
 def test_one_rank_runs_the_multi_gpu_path_over_rccl(cuda):
@@ -90,14 +104,28 @@ def test_a_dead_wire_shows_in_the_exit_code(cuda, fault, code):
 
 
 @pytest.mark.parametrize("world,rank_", [(2, 1), (4, 3), (8, 0), (8, 5), (8, 7)])
-def test_every_ranks_slab_of_the_weak_scaling_grids_keeps_the_headlines_promise(cuda, world, rank_):
-    """The driver's N = 2, 4, 8 runs give every rank one z-slab of a grid that grows with N inside the same physical box
-    (512 x 512 x 1024 ... 1024^3).  The line's assertions -- every voxel of the slab updated by every frame, every TSDF value
-    inside the truncation band -- must hold for ANY rank's slab, not only rank 0's: rehearsed here slab by slab on one GPU
-    (`--emulate-world N --emulate-rank r`; an assertion that fails is a non-zero exit)."""
+def test_every_ranks_slab_of_configs3_keeps_the_headlines_promise(cuda, world, rank_):
+    """The driver's N = 2, 4, 8 runs give every rank one z-slab of BASELINE.json configs[3], 1024^3 @ 2 mm.  The line's
+    assertions -- every voxel of the slab updated by every frame, every TSDF value inside the truncation band -- must hold
+    for ANY rank's slab, not only rank 0's: rehearsed here slab by slab on one GPU (`--emulate-world N --emulate-rank r`;
+    an assertion that fails is a non-zero exit), and the line must name the grid, the voxel size and the partition it ran."""
     rc, lines, err = run([sys.executable, "bench.py", "--emulate-world", str(world), "--emulate-rank", str(rank_)] + QUICK)
     assert rc == 0, err
     d = json.loads(lines[0])
-    assert d["roofline"]["units_per_launch"] == 512 ** 3 and 0.3 < d["roofline"]["frac"] <= 1.0
-    assert d["config"]["grid"] == {2: [512, 512, 1024], 4: [512, 1024, 1024], 8: [1024, 1024, 1024]}[world]
-    assert f"of {d['config']['grid'][2] // world} slices" in d["config"]["partition"]
+    per_rank = 1024 ** 3 // world
+    assert d["roofline"]["units_per_launch"] == per_rank and 0.3 < d["roofline"]["frac"] <= 1.0
+    assert d["config"]["grid"] == [1024, 1024, 1024] and d["config"]["voxel_size_m"] == 0.002 and d["scaling"] == "strong"
+    assert "1024³ grid" in d["metric"] and "1024x1024x1024 @ 2 mm" in d["config"]["workload"]
+    assert f"{world} z-slab(s) of {1024 // world} slices" in d["config"]["partition"] and "configs[3]" in d["config"]["partition"]
+    assert f"rank {rank_} of {world}" in d["config"]["partition"]
+    assert abs(d["value"] - per_rank / d["ms_per_step"] / 1e3) / d["value"] < 2e-3      # the rehearsal's value is the slab's rate
+
+
+def test_weak_scaling_is_still_there_and_says_so(cuda):
+    """`--scaling weak`: per-rank work fixed at the 512^3 grid, the global grid grows with N inside the same physical box."""
+    rc, lines, err = run([sys.executable, "bench.py", "--scaling", "weak", "--emulate-world", "8", "--emulate-rank", "6"] + QUICK)
+    assert rc == 0, err
+    d = json.loads(lines[0])
+    assert d["scaling"] == "weak" and d["config"]["grid"] == [1024, 1024, 1024] and d["config"]["voxel_size_m"] == 0.0025
+    assert "1024x1024x1024 @ 2.5 mm" in d["config"]["workload"] and "weak scaling" in d["config"]["partition"]
+    assert d["roofline"]["units_per_launch"] == 512 ** 3

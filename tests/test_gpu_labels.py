@@ -62,47 +62,92 @@ def test_compose_and_fuse_labels_match_oracle(cuda, oracle):
     assert np.all(ref_w[ref_l != 0] > 0)
 
 
-def test_config4_slab_of_2048_cube_with_labels(cuda, oracle):
-    """BASELINE configs[4] rehearsed on one GPU: rank 2 of 8 of a 2048^3 @ 2 mm grid (a 2048x2048x256
-    slab, 8.6 GB TSDF+weight + 10.7 GB label state) takes one labelled frame; three 2-slice samples are
-    checked against the oracle bit for bit (64-bit indexing: slab offsets exceed 2^31 elements)."""
+def _config4_frames(oracle, scene, n_frames, seed=9):
+    """n_frames labelled frames of the S-surf orbit: (cam2world, depth, label image, score image); the instance masks of
+    every third frame carry their classes in reverse order, so background evidence accumulates and labels get re-adopted."""
+    rng = np.random.default_rng(seed)
+    frames = []
+    for k in range(n_frames):
+        c2w = scene.pose(k, n=48)
+        depth = scene.depth(c2w, quantize=True)
+        masks, labels, scores = instance_masks(rng, 6)
+        if k % 3 == 2:
+            labels[:] = labels[::-1]
+        lab, sc = oracle.compose_labels(masks, labels, scores)
+        frames.append((c2w, depth, lab, sc))
+    return frames
+
+
+@pytest.mark.parametrize("rank_", [1, 2])
+def test_config4_whole_slab_every_voxel(cuda, oracle, rank_):
+    """BASELINE configs[4] on one GPU, EVERY voxel: one rank's slab of a 2048^3 @ 2 mm grid cut eight ways -- 2048 x 2048 x 256
+    voxels, 8.6 GB TSDF + weight and 10.7 GB label state, dim_y = 2048 (twice the reference kernel's block limit,
+    so the CPU oracle is the only checker), byte offsets beyond 2^32 -- rank 1 (z_begin = 256: the slab that holds the visible cap
+    of the sphere, i.e. the truncation band and nearly all label evidence) and rank 2 (z_begin = 512: free space in front of the
+    wall, the sphere's shadow and the band where the sphere leaves the view) -- takes 35 labelled frames (one more than a
+    32-frame pass) through the path a config-5 run takes, tsdf_integrate_frames_labels_device, with the classification
+    decided per launch (variant 0) and forced (variant 8: classify_brick_list + integrate_brick_list<NT, LABELS>), and
+    through the per-frame pair tsdf_integrate_device + tsdf_integrate_labels_device.  TSDF bits, weights, labels, Fp
+    and Bp of all 1 073 741 824 voxels are compared with the oracle (all host threads: rows are independent).
+    The evidence rule being matched: ref src/ObjectPoint.cpp:190-219, :149-154; index width: src/tsdf.cu:52."""
+    import time
     D, vs = 2048, 0.002
     dims = (D, D, D)
-    zb, ze = 2 * D // 8, 3 * D // 8      # the slab that holds the visible cap of the sphere
+    zb, ze = rank_ * D // 8, (rank_ + 1) * D // 8
+    n_frames = 35
     origin = np.array([-2.048, -2.048, 0.4], np.float32)
     cfg = capi.make_config(dims, vs, origin, z_begin=zb, z_end=ze)
     scene = synth.SurfScene(dims, vs, origin)
-    rng = np.random.default_rng(9)
-    c2w = scene.pose(2, n=16)
-    depth = scene.depth(c2w, quantize=True)
-    masks, labels, scores = instance_masks(rng, 6)
-    want_lab, want_sc = oracle.compose_labels(masks, labels, scores)
+    frames = _config4_frames(oracle, scene, n_frames)
+    poses = np.stack([f[0] for f in frames])
+    n = D * D * (ze - zb)
+    t0 = time.time()
+    ref_t, ref_w = oracle.init_grid(dims, zb, ze)
+    ref_l, ref_f, ref_b = np.zeros(n, np.uint16), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    upd = seen = 0
+    for c2w, depth, lab, sc in frames:
+        upd += oracle.integrate(cfg.cam_K, c2w, depth, dims, origin, vs, cfg.trunc_margin, ref_t, ref_w, z_begin=zb, z_end=ze)
+        seen += oracle.integrate_labels(cfg.cam_K, c2w, depth, lab, sc, dims, origin, vs, cfg.trunc_margin,
+                                        ref_l, ref_f, ref_b, z_begin=zb, z_end=ze)
+    t_oracle = time.time() - t0
+    if rank_ == 1:
+        assert upd > 10_000_000 * n_frames and seen > 20_000_000, (upd, seen)
+        assert np.count_nonzero(ref_b) > 100_000 and len(np.unique(ref_l)) > 5    # background evidence and several classes
+    else:
+        assert upd > 10_000_000 and seen > 100_000, (upd, seen)
+    keep = [(cuda.from_numpy(d).cuda(), cuda.from_numpy(l).cuda(), cuda.from_numpy(s_).cuda()) for _, d, l, s_ in frames]
+
+    def compare(vol, what):
+        t, w = vol.download()
+        assert np.array_equal(w, ref_w), f"{what}: weights differ at {np.flatnonzero(w != ref_w)[:4]}"
+        bad = np.flatnonzero(t.view(np.uint32) != ref_t.view(np.uint32))
+        assert bad.size == 0, f"{what}: {bad.size} TSDF values differ, first at {bad[:4]}"
+        del t, w
+        lab, fp, bp = vol.download_labels()
+        assert np.array_equal(lab, ref_l), f"{what}: labels differ at {np.flatnonzero(lab != ref_l)[:4]}"
+        assert np.array_equal(fp.view(np.uint32), ref_f.view(np.uint32)), f"{what}: Fp differs"
+        assert np.array_equal(bp.view(np.uint32), ref_b.view(np.uint32)), f"{what}: Bp differs"
+
+    t0 = time.time()
+    for variant in (0, 8):
+        with capi.Volume(cfg) as vol:
+            vol.set_kernel_variant(variant)
+            vol.labels_enable(0.5)
+            vol.integrate_frames_labels_device([d.data_ptr() for d, _, _ in keep], [l.data_ptr() for _, l, _ in keep],
+                                               [s_.data_ptr() for _, _, s_ in keep], poses)
+            frac, idle = vol.classification_info()
+            if variant == 8:
+                assert idle == 0 and frac > 0.5, (frac, idle)   # both passes went over the brick work list and its claims
+            compare(vol, f"fused, variant {variant}")
     with capi.Volume(cfg) as vol:
         vol.labels_enable(0.5)
-        m_dev, d_dev = cuda.from_numpy(masks).cuda(), cuda.from_numpy(depth).cuda()
-        lab_dev = cuda.empty((480, 640), dtype=cuda.uint16, device="cuda")
-        sc_dev = cuda.empty((480, 640), dtype=cuda.float32, device="cuda")
-        vol.compose_labels(m_dev.data_ptr(), labels, scores, lab_dev.data_ptr(), sc_dev.data_ptr())
-        vol.integrate_labels_device(d_dev.data_ptr(), lab_dev.data_ptr(), sc_dev.data_ptr(), c2w)
-        vol.integrate_device(d_dev.data_ptr(), c2w)
-        lab, fp, bp = vol.download_labels()
-        # check the three slice pairs that received the most label evidence, plus the slab's first pair
-        per_slice = np.count_nonzero(lab.reshape(ze - zb, -1), axis=1)
-        picks = sorted(set([0] + [int(z) for z in np.argsort(per_slice)[-3:]]))
-        seen = 0
-        for zl in picks:
-            zl = min(zl, ze - zb - 2)
-            z0 = zb + zl
-            st, sw = oracle.init_grid(dims, z0, z0 + 2)
-            sl, sf, sb = np.zeros(st.size, np.uint16), np.zeros(st.size, np.float32), np.zeros(st.size, np.float32)
-            oracle.integrate(cfg.cam_K, c2w, depth, dims, origin, vs, cfg.trunc_margin, st, sw, z_begin=z0, z_end=z0 + 2)
-            seen += oracle.integrate_labels(cfg.cam_K, c2w, depth, want_lab, want_sc, dims, origin, vs, cfg.trunc_margin,
-                                            sl, sf, sb, z_begin=z0, z_end=z0 + 2)
-            gt, gw = vol.copy_slices(zl, 2)
-            lo, hi = zl * D * D, (zl + 2) * D * D
-            assert np.array_equal(gw, sw) and np.array_equal(gt.view(np.uint32), st.view(np.uint32))
-            assert np.array_equal(lab[lo:hi], sl) and np.array_equal(fp[lo:hi], sf) and np.array_equal(bp[lo:hi], sb)
-    assert seen > 1000 and np.count_nonzero(lab) > 10000, (seen, int(np.count_nonzero(lab)))
+        vol.set_deferral(0)
+        for (c2w, _, _, _), (d, l, s_) in zip(frames, keep):
+            vol.integrate_labels_device(d.data_ptr(), l.data_ptr(), s_.data_ptr(), c2w)
+            vol.integrate_device(d.data_ptr(), c2w)
+        compare(vol, "one launch per call")
+    print(f"configs[4] slab of rank {rank_}: {n} voxels x {n_frames} frames, {upd} updates, {seen} label events; oracle {t_oracle:.0f} s "
+          f"({oracle.max_threads()} threads), three device paths + compares {time.time() - t0:.0f} s")
 
 
 @pytest.mark.parametrize("shape", [None, (2, 8, 4), (2, 5, 6)])   # the wavefront brick: the library's choice, spanning slices
