@@ -33,7 +33,8 @@ class Oracle:
     """CPU restatement (kind "port" in bench.py's cpu_baseline)."""
 
     def __init__(self):
-        path = os.path.join(_HERE, "liboracle.so")
+        # TSDF_ORACLE_LIB: another build of the same sources (the sanitizer build, oracle/_asan/liboracle_asan.so)
+        path = os.environ.get("TSDF_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")
         if not os.path.isfile(path):
             build(ref=False)
         L = self.lib = C.CDLL(path)

@@ -1,7 +1,7 @@
 // host_derive.h -- what the host derives from a configuration and a pose before a launch: the wavefront brick, the depth tile
 // edge and the guards / margins that make the kernels' shortcuts exact ("Why each shortcut is exact").
-// Plain C++ (no HIP, no device types): tsdf_capi.hip includes it for the product, and oracle/asan_host.cpp compiles it with
-// -fsanitize=address,undefined for the CPU sanitizer run (`make -C oracle asan`, tests/test_sanitizers.py).
+// Plain C++ (no HIP, no device types): tsdf_capi.hip includes it for the product, and the CPU sanitizer run compiles it by
+// itself with -fsanitize=address,undefined (tests/test_sanitizers.py).
 #pragma once
 #include <algorithm>
 #include <cmath>
