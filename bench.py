@@ -84,6 +84,11 @@ def parse():
     ap.add_argument("--tum-dir", default="", help="traj: directory of the TUM fr3_office sequence (holding depth/<stamp>.png as "
                     "result/rgbd/associations.txt names them); when it exists the keyframes' real 16-bit depth frames are integrated "
                     "(value / 5000 m) instead of the rendered ones.  No dataset ships with the repository and none is fetched.")
+    ap.add_argument("--labels", type=int, default=0,
+                    help="ssurf: per-voxel label fusion in the same passes (tsdf_integrate_frames_labels_device, BASELINE.json configs[4]) "
+                         "with this many synthetic instance masks per frame in MaskRCNN's output format (uint8 {0,255}, label 1..80, "
+                         "score in (0.8, 1]), composed on the device.  configs[4] as one rank sees it: --workload ssurf --grid 2048 "
+                         "--voxel-mm 2 --emulate-world 8 --emulate-rank 1 --labels 6")
     ap.add_argument("--strong-leg", action="store_true",
                     help="N > 1 (or --dist-world1): run the strong_512 / n1_same_job legs even with --no-extras (tests)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
@@ -340,6 +345,12 @@ def child_args_for(args, workload=None, mode=None, variant=None, grid=None, step
         a += ["--tum-dir", args.tum_dir]
     if args.depth_cache:
         a += ["--depth-cache", args.depth_cache]
+    if args.labels and (workload or args.workload) == args.workload:
+        a += ["--labels", str(args.labels)]
+    if args.emulate_world > 1 and grid is None:
+        a += ["--emulate-world", str(args.emulate_world), "--emulate-rank", str(args.emulate_rank)]
+    if args.voxel_mm > 0 and grid is None:
+        a += ["--voxel-mm", str(args.voxel_mm)]
     return a
 
 
@@ -381,15 +392,21 @@ PMC_KERNEL_NAMES = {}          # kernel substring -> the kernel's full name as t
 N_SIMDS = 1024                 # 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
 
 
+VALU_PEAK_CYCLES_PER_INST = 2.0   # a SIMD issues at most one wave64 VALU instruction per 2 cycles (32 lanes per cycle: MI355X_MICROARCH.md,
+                                  # "v_fma_f32 (wave64) 2 cyc"; 1024 SIMDs x 32 lanes x 2 flop x 2.4 GHz = the 157 TFLOP/s fp32 vector peak)
+
+
 def measure_valu(kernel_substr, child_args, fpl=32):
-    """What an issue-bound launch is measured against, from counters alone (no modelled instruction price): the share of
-    the launch's SIMD-cycles in which a VALU instruction was executing -- SQ_ACTIVE_INST_VALU counts, per wavefront, the
-    quad-cycles it spends in VALU instructions (MI355X_MICROARCH.md, "s_memtime tick vs SQ PMC units"; a SIMD executes one
-    wavefront's VALU instruction at a time, so the sum over a SIMD's wavefronts cannot exceed its cycles) -- over
-    GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs: rocprofv3's own VALUBusy formula.  The scalar unit likewise (SQ_ACTIVE_INST_SCA,
-    one unit per CU)."""
-    r, why = _pmc_pass(["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA",
-                        "SQ_WAIT_ANY", "GRBM_GUI_ACTIVE"], kernel_substr, child_args, _child_shape(child_args, fpl)[0])
+    """What an issue-bound launch is measured against, from counters and one hardware constant (no modelled instruction price):
+    valu_issue_frac = SQ_INSTS_VALU (wave instructions) x 2 cycles -- the SIMDs' peak issue rate -- / (GRBM_GUI_ACTIVE / 8 XCDs
+    x 1024 SIMDs): the share of the chip's VALU issue slots the launch used, <= 1 by construction.  (No counter of this chip gives
+    "cycles the VALU was busy": SQ_ACTIVE_INST_VALU sums, per wavefront, the quad-cycles it spends in VALU instructions, and the
+    instructions of a SIMD's wavefronts overlap in its pipeline -- that quotient read 0.92 on S-surf and 1.01 on the trajectory.  What
+    the instruction mix of these kernels costs per instruction -- compares, selects, conversions, packed operations and reciprocals
+    issue slower than a plain multiply-add -- is measured by tools/microbench/valu_rate.hip: 3.5 cycles on average)
+    Beside it, how the resident wavefronts spent their time: executing, waiting for memory / barriers, stalled at issue."""
+    r, why = _pmc_pass(["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY",
+                        "SQ_WAIT_INST_ANY", "GRBM_GUI_ACTIVE"], kernel_substr, child_args, _child_shape(child_args, fpl)[0])
     if r is None:
         return None, why
     PMC_KERNEL_NAMES[kernel_substr] = r["kernel_name"]
@@ -398,20 +415,21 @@ def measure_valu(kernel_substr, child_args, fpl=32):
         return None, "GRBM_GUI_ACTIVE read 0"
     steps = _child_shape(child_args, fpl)[1]
     per = r["SQ_INSTS_VALU"][1] * fpl / float(steps) if fpl > 1 else 1.0      # dispatches -> launches of fpl frames
-    valu_cyc = r["SQ_ACTIVE_INST_VALU"][0] * 4.0
-    return {"valu_issue_frac": round(valu_cyc / (cyc * N_SIMDS), 4),
-            "salu_busy_frac": round(r["SQ_ACTIVE_INST_SCA"][0] * 4.0 / (cyc * N_SIMDS / 4.0), 4),
-            "cycles_per_valu_inst": round(valu_cyc / max(r["SQ_INSTS_VALU"][0], 1.0), 3),
+    wave_cyc = max(r["SQ_WAVE_CYCLES"][0], 1.0)
+    return {"valu_issue_frac": round(r["SQ_INSTS_VALU"][0] * VALU_PEAK_CYCLES_PER_INST / (cyc * N_SIMDS), 4),
+            "valu_peak_cycles_per_inst": VALU_PEAK_CYCLES_PER_INST,
             "valu_insts_per_launch": int(r["SQ_INSTS_VALU"][0] * per), "salu_insts_per_launch": int(r["SQ_INSTS_SALU"][0] * per),
+            "salu_per_valu": round(r["SQ_INSTS_SALU"][0] / max(r["SQ_INSTS_VALU"][0], 1.0), 3),
             "waves_per_launch": int(r["SQ_WAVES"][0] * per), "kernel_cycles": int(cyc * per),
             "mean_waves_per_simd": round(r["SQ_WAVE_CYCLES"][0] * 4.0 / (cyc * N_SIMDS), 2),
-            "wait_any_frac_of_wave_cycles": round(r["SQ_WAIT_ANY"][0] / max(r["SQ_WAVE_CYCLES"][0], 1.0), 4),
-            "source": "bench.py measure_valu: rocprofv3 --pmc counters only (no modelled constant)",
+            "wave_time": {"executing": round(r["SQ_ACTIVE_INST_ANY"][0] / wave_cyc, 4), "waiting_memory_or_barrier": round(r["SQ_WAIT_ANY"][0] / wave_cyc, 4),
+                          "stalled_at_issue": round(r["SQ_WAIT_INST_ANY"][0] / wave_cyc, 4)},
+            "source": "bench.py measure_valu: rocprofv3 --pmc counters of a short child run; the 2-cycle peak from MI355X_MICROARCH.md",
             "note": "one rocprofv3 --pmc pass over a short child run, means over "
                     f"{r['SQ_INSTS_VALU'][1]} dispatches ({steps} consecutive frames; per-launch figures scaled to {fpl} frames): "
-                    "valu_issue_frac = SQ_ACTIVE_INST_VALU x 4 (quad-cycles -> cycles in which a wavefront's VALU instruction "
-                    "executes) / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), measured, <= 1 by construction; cycles_per_valu_inst = the same "
-                    "cycles / SQ_INSTS_VALU (wave instructions); salu_busy_frac = SQ_ACTIVE_INST_SCA x 4 / (cycles x 256 scalar units)"}, None
+                    "valu_issue_frac = SQ_INSTS_VALU x 2 cycles (peak issue rate of a SIMD) / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), <= 1 by "
+                    "construction; wave_time = SQ_ACTIVE_INST_ANY, SQ_WAIT_ANY, SQ_WAIT_INST_ANY over SQ_WAVE_CYCLES (disjoint shares of the "
+                    "resident wavefronts' time)"}, None
 
 
 def main():
@@ -473,8 +491,47 @@ def main():
     d_dev = [torch.from_numpy(d).cuda() for d in W.depths]
     H, Wd = W.depths[0].shape
 
+    # ---- per-voxel label fusion in the same passes (--labels K; BASELINE.json configs[4]) --------------------------------------
+    lab_dev = sc_dev = None
+    if args.labels > 0:
+        assert args.workload == "ssurf" and fpl > 1, "--labels rides on the fused S-surf sequence"
+        vol.labels_enable(0.5)
+        rng = np.random.default_rng(9)
+        lab_dev, sc_dev = [], []
+        for k in range(len(d_dev)):
+            # K instance rectangles that drift across the image with the orbit (the scene's sphere keeps the middle of it)
+            masks = np.zeros((args.labels, H, Wd), np.uint8)
+            for m in range(args.labels):
+                y0 = int((0.08 + 0.11 * m) * H + 6 * math.sin(0.2 * k + m)) % max(H - 120, 1)
+                x0 = int((0.05 + 0.13 * m) * Wd + 9 * math.cos(0.15 * k + m)) % max(Wd - 160, 1)
+                masks[m, y0:y0 + H // 3 + 17 * m, x0:x0 + Wd // 3 + 23 * m] = 255
+            labels_k = ((np.arange(args.labels) * 7 + (k // 16)) % 80 + 1).astype(np.uint16)       # classes change along the sequence
+            scores_k = rng.uniform(0.8, 1.0, args.labels).astype(np.float32)
+            m_dev = torch.from_numpy(masks).cuda()
+            l_d = torch.empty((H, Wd), dtype=torch.uint16, device="cuda")
+            s_d = torch.empty((H, Wd), dtype=torch.float32, device="cuda")
+            vol.compose_labels(m_dev.data_ptr(), labels_k, scores_k, l_d.data_ptr(), s_d.data_ptr())
+            vol.sync()
+            lab_dev.append(l_d)
+            sc_dev.append(s_d)
+            del m_dev
+        lab_stream = torch.cuda.Stream()
+        vol.set_stream(lab_stream.cuda_stream)       # so that torch events on this stream bracket the library's launches
+
+    def run_block_labels(v, start, n):
+        poses, idx = W.block(start, n)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(lab_stream)
+        v.integrate_frames_labels_device([d_dev[i].data_ptr() for i in idx], [lab_dev[i].data_ptr() for i in idx],
+                                         [sc_dev[i].data_ptr() for i in idx], poses)
+        e1.record(lab_stream)
+        e1.synchronize()
+        return e0.elapsed_time(e1)
+
     def run_block(v, start, n, Wl=None, ddev=None):
         """n consecutive steps queued back to back on the handle's stream; device milliseconds (HIP events there)."""
+        if args.labels > 0 and v is vol and Wl is None:
+            return run_block_labels(v, start, n)
         Wl, ddev = Wl or W, ddev or d_dev
         poses, idx = Wl.block(start, n)
         if len(ddev) == 1:
@@ -503,8 +560,9 @@ def main():
         Wl, ddev = Wl or W, ddev or d_dev
         fpl_ = v.frames_per_launch
         n_warm = max(args.warmup, 2 * fpl_, 8)
-        run_block(v, 0, n_warm, Wl, ddev)
-        cal_ms = run_block(v, n_warm, K, Wl, ddev)     # calibration block (also warm): how long K steps take
+        own = (None, None) if (Wl is W and ddev is d_dev) else (Wl, ddev)
+        run_block(v, 0, n_warm, *own)
+        cal_ms = run_block(v, n_warm, K, *own)         # calibration block (also warm): how long K steps take
         done = n_warm + K
         repeats = max(1, int(math.ceil(1.2 * min_ms / max(cal_ms, 1e-3))))   # 20 % margin: the calibration block may run slow
         if dist is not None:   # every rank times the same number of blocks
@@ -515,12 +573,12 @@ def main():
         # idle for ~0.4 ms between repeats while the host drained, returned and came back: 5 % at --steps 20); with a depth frame
         # per pose the call's arguments (K x repeats device pointers and poses) are marshalled ahead of the timed region
         timed_call = None
-        if len(ddev) > 1:
+        if len(ddev) > 1 and not (args.labels > 0 and v is vol):
             poses_t, idx_t = Wl.block(done, K * repeats)
             timed_call = v.frames_timed_call([ddev[i].data_ptr() for i in idx_t], poses_t)
         fence()
         t0 = time.perf_counter()
-        k_ms = timed_call() if timed_call is not None else run_block(v, done, K * repeats, Wl, ddev)
+        k_ms = timed_call() if timed_call is not None else run_block(v, done, K * repeats, None if Wl is W else Wl, None if ddev is d_dev else ddev)
         fence()
         wall_ = time.perf_counter() - t0
         tt = torch.tensor([wall_, k_ms], dtype=torch.float64, device=on_dev)
@@ -549,20 +607,27 @@ def main():
     # several frames per pass over a scene with free / unseen space: what a launch touches (its voxels updated by at least one
     # of its frames) is counted, not bounded -- every launch of one pass over the step sequence on a fresh volume, weights > 0
     # counted on the device; per fpl frames, like the measured traffic it is compared with
-    touched_per_launch = None
+    touched_per_launch, labelled_per_launch = None, 0.0
     if fpl > 1 and not W.full_coverage and world == 1:
         nz_s = ze - zb
         t_dev = torch.empty(n_slab, dtype=torch.float32, device="cuda")
         w_dev = torch.empty(n_slab, dtype=torch.float32, device="cuda")
         seq = W.n_pose if W.n_pose >= 2 * fpl else 3 * fpl        # the frames the traffic children run
-        total = 0
+        total = labelled = 0
+        lab_host = np.empty(n_slab, np.uint16) if args.labels > 0 else None
         for start in range(0, seq, fpl):
             vol.reset()
+            if args.labels > 0:
+                vol.labels_enable(0.5)           # clears the label state
             run_block(vol, start, min(fpl, seq - start))
             vol.copy_slices_to_device(0, nz_s, t_dev.data_ptr(), w_dev.data_ptr())
             total += int(torch.count_nonzero(w_dev))
+            if args.labels > 0:
+                capi.check(vol.lib.tsdf_download_labels(vol._h, lab_host.ctypes.data, None, None), "tsdf_download_labels")
+                labelled += int(np.count_nonzero(lab_host))
         touched_per_launch = total * fpl / float(seq)
-        del t_dev, w_dev
+        labelled_per_launch = labelled * fpl / float(seq)
+        del t_dev, w_dev, lab_host
 
     # ---- N > 1: north_star's "512^3 grid at 1, 2, 4 and 8 GPUs" beside the headline, and the N = 1 figure both scale from ---
     strong_512 = n1_here = None
@@ -688,11 +753,18 @@ def main():
         frames_per = K / (full + (1 if rem else 0))
         units_per_launch = touched_per_launch if touched_per_launch is not None else min(float(n_slab), frames_per * n_upd_per_frame)
         alg_bytes = 16.0 * units_per_launch + frames_per * frame_bytes
+        if args.labels > 0:
+            # label state of a voxel that received evidence in the launch: label u16 + Fp f32 + Bp f32, read and written (repeated
+            # evidence within a launch is a read-modify-write per frame in the kernel; L2 serves the repeats), and the frame's
+            # label + score images beside its depth
+            alg_bytes += 20.0 * labelled_per_launch + frames_per * 6.0 * H * Wd
         unit_name = ("voxel updated by at least one frame of the launch (4 B TSDF + 4 B weight, read once and written once per "
                      "launch)" + ("" if touched_per_launch is None and W.full_coverage else
                                   "; counted per launch on a fresh volume over one pass of the pose sequence, mean per 32 frames" if touched_per_launch is not None else
                                   "; bounded by frames x updates per frame (N > 1: not counted)"))
-        bytes_model = "16 B x voxels touched by the launch + frames per launch x (4*H*W + 100)"
+        bytes_model = "16 B x voxels touched by the launch + frames per launch x (4*H*W + 100)" + (
+            "" if args.labels <= 0 else " + 20 B x voxels that received label evidence in the launch (u16 label + f32 Fp + f32 Bp, read and "
+            "written) + frames per launch x 6*H*W (label and score images)")
     kernel_ms = kernel_ms_total / launches
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
     if fpl == 1:
@@ -703,15 +775,19 @@ def main():
         # what the library launches for a known sequence: over the brick work list while the previous launch's claims pay
         # (decided per launch; the S-band and variant 7 never do), else per voxel
         listed = args.workload in ("ssurf", "traj", "sfull") and variant != 7
-        kname = ("tsdfk::integrate_brick_list<false, false, false> over the work list of tsdfk::classify_brick_list (decided per launch)"
+        kname = (f"tsdfk::integrate_brick_list<false, {'true' if args.labels > 0 else 'false'}, false> over the work list of tsdfk::classify_brick_list (decided per launch)"
                  if listed else "tsdfk::integrate_multi_inline<1, true, false, false, false> (every voxel projected)")
         ksub = "integrate_brick_list<" if listed else "integrate_multi_inline<"
 
     traffic, traffic_note = None, "not measured (--no-traffic)"
-    if not args.no_traffic and world == 1 and args.emulate_world <= 1:
+    main_valu = None
+    if not args.no_traffic and world == 1 and (args.emulate_world <= 1 or args.labels > 0):
         # the child launches what the timed region launched: single frames, or passes of the same number of frames
-        traffic, traffic_note = measure_traffic(ksub, child_args_for(args, variant=variant, steps=6 if fpl == 1 else W.n_pose if W.n_pose >= 2 * fpl else 3 * fpl),
-                                                fpl=fpl, wide_reads="brick_list" not in ksub)
+        ca_main = child_args_for(args, variant=variant, steps=6 if fpl == 1 else W.n_pose if W.n_pose >= 2 * fpl else 3 * fpl)
+        traffic, traffic_note = measure_traffic(ksub, ca_main, fpl=fpl, wide_reads="brick_list" not in ksub)
+        if fpl > 1:      # these launches are bound by instruction issue: the measured VALU share beside the bytes
+            vu, vu_note = measure_valu(ksub, ca_main, fpl)
+            main_valu = vu if vu is not None else {"error": vu_note}
 
     # the kernel's name as the profiler printed it in this run's child passes (what profiles/*_kernel_stats.csv lists); without
     # such a pass (N > 1, --no-traffic) the name the source gives it
@@ -762,6 +838,17 @@ def main():
                      "note": "per-rank slab launch; kernel_ms = HIP-event time of the timed region (events on the handle's "
                              "stream) / launches; achieved = algorithmic_bytes_per_launch / kernel_ms"},
     }
+    if main_valu is not None:
+        line["roofline"]["valu"] = main_valu
+        if traffic is not None:
+            line["roofline"]["hbm_measured_GBps"] = round(traffic / (kernel_ms * 1e-3) / 1e9, 1)
+            line["roofline"]["hbm_measured_frac"] = round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    if args.labels > 0:
+        line["labels"] = {"instance_masks_per_frame": args.labels, "voxels_labelled_per_launch": int(labelled_per_launch),
+                          "label_state_bytes_per_voxel": 10,
+                          "note": "Integrate + per-voxel label fusion in the same passes (tsdf_integrate_frames_labels_device; rule: "
+                                  "ref src/ObjectPoint.cpp:190-219 per voxel, DESIGN.md N3); label + score images composed on the device "
+                                  "from synthetic instance masks in MaskRCNN's output format"}
     if multi:
         # what a SCALE record must show: how many ranks the communicator saw, through which backend, what the halo costs, and the
         # job's rate against N GPUs' HBM (SURVEY.md section 8d "scaling table": Mvox/s and % of (G x 8 TB/s))

@@ -25,6 +25,7 @@
 
 #include "pose_math.h"
 #include "host_derive.h"
+#include "host_copy.h"
 #include "frame_store.h"
 #include "tsdf_kernels.hip.h"
 #include "tsdf_multiframe.hip.h"
@@ -76,6 +77,12 @@ constexpr bool kExperiments = false;
 #define TSDF_BRICK_NT 0
 #endif
 constexpr bool kBrickNT = TSDF_BRICK_NT != 0;
+// How classify_brick_list deals super-bricks to the 64 sub-lists (tsdf_multiframe.hip.h, list_bucket): 0 = hashed, 1 = the XCD
+// by image-row wedges.
+#ifndef TSDF_WEDGE_MODE
+#define TSDF_WEDGE_MODE 0
+#endif
+constexpr int kWedgeMode = TSDF_WEDGE_MODE;
 
 }  // namespace
 
@@ -142,6 +149,7 @@ struct tsdf_volume {
     uint4 *d_work;               // work list of the current fused brick launch: {brick, slice group, free frames, skipped frames}
     size_t work_entries;         // per live brick (classify_brick_list); capacity = every brick of the slab
     int64_t work_nsuper, work_bucket_supers;   // super-bricks of the shape the list was sized for; most of them in one sub-list
+    int work_wedge_mode = -1;                  // ... and the list_bucket mode they were counted under
     // optional diagnostic counters (tsdf_shortcut_stats)
     unsigned int *d_shortcut_stats;
     // adaptive use of the classification: claims of the last classifying launch, read back without blocking
@@ -669,9 +677,22 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
     if (classify && !v->d_claims) {
         // the launch's counter block (tsdf_multiframe.hip.h, kListBuckets): per bucket the lengths of its brick sub-list and
         // its share of the claims, cleared by the table kernel below; behind it the frames' table for classify_patch
-        HIP_TRY(hipMalloc((void **)&v->d_claims, tsdfk::kCounterBytes + sizeof(tsdfk::ClassPoseTable)));
-        HIP_TRY(hipHostMalloc((void **)&v->h_claims, tsdfk::kCounterBytes, hipHostMallocDefault));
-        HIP_TRY(hipEventCreateWithFlags(&v->claims_done, hipEventDisableTiming));
+        // all three or none: a launch that finds d_claims set relies on the host mirror and the event being there too
+        unsigned long long *dc = nullptr;
+        unsigned char *hc = nullptr;
+        hipEvent_t ev = nullptr;
+        hipError_t e = hipMalloc((void **)&dc, tsdfk::kCounterBytes + sizeof(tsdfk::ClassPoseTable));
+        if (e == hipSuccess) e = hipHostMalloc((void **)&hc, tsdfk::kCounterBytes, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            if (ev) (void)hipEventDestroy(ev);
+            if (hc) (void)hipHostFree(hc);
+            if (dc) (void)hipFree(dc);
+            return fail(TSDF_ERR_HIP, "claim counters: %s", hipGetErrorString(e));
+        }
+        v->d_claims = reinterpret_cast<decltype(v->d_claims)>(dc);
+        v->h_claims = reinterpret_cast<decltype(v->h_claims)>(hc);
+        v->claims_done = ev;
     }
     if (count_claims) mi.common.claim_counter = v->d_claims + 1;   // bucket 0's claims word (the pre-pass adds the bucket's offset)
     if (classify) {
@@ -702,12 +723,26 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
         bl.nsy = (mi.common.brick_groups + tsdfk::kSuperBY - 1) / tsdfk::kSuperBY;
         bl.nsz = (nz_groups + tsdfk::kSuperBZ - 1) / tsdfk::kSuperBZ;
         const int64_t n_super = (int64_t)bl.nsx * bl.nsy * bl.nsz;
-        // a sub-list must hold every brick of every super-brick its hash deals to it: counted exactly, once per grid shape
-        if (v->work_nsuper != n_super) {
+        bl.wedge_mode = kWedgeMode;
+#ifdef TSDF_EXPERIMENTS
+        if (const char *e = std::getenv("TSDF_WEDGE_MODE")) bl.wedge_mode = std::atoi(e);     // A/B knob of the measurement build
+#endif
+        bl.super_h = tsdfk::kSuperBY * mi.common.brick_r;
+        bl.super_d = tsdfk::kSuperBZ * mi.common.brick_s;
+        bl.wedge_oy = (int)std::lround(std::fmax(-30000.0, std::fmin(30000.0, (double)c.origin[1] / c.voxel_size)));
+        bl.wedge_oz = (int)std::lround(std::fmax(-30000.0, std::fmin(30000.0, (double)c.origin[2] / c.voxel_size + c.z_begin)));
+        bl.fy_px = (int)std::lround(std::fmax(1.0, std::fmin(16000.0, std::fabs((double)c.cam_K[4]))));
+        if (!(c.voxel_size > 0) || std::isnan(c.origin[1]) || std::isnan(c.origin[2])) bl.wedge_mode = 0;
+        // a sub-list must hold every brick of every super-brick list_bucket deals to it: counted exactly, once per grid shape
+        if (v->work_nsuper != n_super || v->work_wedge_mode != bl.wedge_mode) {
             std::vector<int64_t> per((size_t)tsdfk::kListBuckets, 0);
-            for (int64_t id = 0; id < n_super; ++id) ++per[(size_t)(((uint32_t)id * 2654435761u) >> 26)];   // as classify_brick_list
+            for (int64_t id = 0; id < n_super; ++id) {      // the index order of classify_brick_list: slice groups fastest, then x, then y
+                const int sz = (int)(id % bl.nsz), sx = (int)((id / bl.nsz) % bl.nsx), sy = (int)((id / bl.nsz) / bl.nsx);
+                ++per[(size_t)tsdfk::list_bucket((unsigned int)id, sx, sy, sz, bl)];
+            }
             v->work_bucket_supers = *std::max_element(per.begin(), per.end());
             v->work_nsuper = n_super;
+            v->work_wedge_mode = bl.wedge_mode;
         }
         const int64_t cap = v->work_bucket_supers * tsdfk::kSuperBricks;
         const int64_t total = cap * tsdfk::kListBuckets;
@@ -1251,7 +1286,7 @@ int tsdf_integrate(tsdf_volume *v, const float *depth_host, const float cam2worl
     // caller's frame -> pinned ring -> a frame slot in HBM (copy stream); the caller may free depth_host when we return
     int slot = -1;
     void *dev = nullptr;
-    rc = stage_begin(v, img, [&](float *pinned) { std::memcpy(pinned, depth_host, img); }, &slot, &dev);
+    rc = stage_begin(v, img, [&](float *pinned) { tsdf_host::copy_to_pinned(pinned, depth_host, img); }, &slot, &dev);
     if (rc) return rc;
     if (defer) {
         // collect: pose composed now; launched defer_n at a time (or at the next call that observes the volume) as one fused
@@ -1311,27 +1346,49 @@ int tsdf_integrate_u16(tsdf_volume *v, const uint16_t *raw_host, float depth_fac
     // second slot, which is the frame Integrate reads
     int raw_slot = -1, slot = -1;
     void *raw_dev = nullptr, *dev = nullptr;
-    rc = stage_begin(v, px * sizeof(uint16_t), [&](float *pinned) { std::memcpy(pinned, raw_host, px * sizeof(uint16_t)); }, &raw_slot, &raw_dev);
+    rc = stage_begin(v, px * sizeof(uint16_t), [&](float *pinned) { tsdf_host::copy_to_pinned(pinned, raw_host, px * sizeof(uint16_t)); }, &raw_slot, &raw_dev);
     if (rc) return rc;
+    // a failure from here on hands the slots it holds back to the (shared, per-device) store: they would otherwise stay held until
+    // the handle is destroyed and count against every other handle's share
+    auto give_back = [&](int failed) {
+        int held[2], n = 0;
+        if (raw_slot >= 0) held[n++] = raw_slot;
+        if (slot >= 0) held[n++] = slot;
+        if (n > 0) {
+            (void)hipEventRecord(v->pend_copied, v->copy_stream);      // whatever was queued on the copy stream has read them by then
+            tsdf_store::slots_release_after(v->store, &v->store->frames, held, n, &v->pend_copied, v);
+        }
+        return failed;
+    };
     rc = store_slot(v, &v->store->frames, v->copy_stream, &slot, &dev);
-    if (rc) return rc;
+    if (rc) { slot = -1; return give_back(rc); }
     hipLaunchKernelGGL(tsdfk::depth_u16_to_f32, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, v->copy_stream,
                        static_cast<const uint16_t *>(raw_dev), static_cast<float *>(dev), v->cfg.im_height, v->cfg.im_width,
                        1.0f / depth_factor, row_step, col_step);   // ref: examples/label_instance_rgbd.cpp:99-100 (fp32 reciprocal)
-    HIP_TRY(hipGetLastError());
+    {
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess) return give_back(fail(TSDF_ERR_HIP, "depth_u16_to_f32: %s", hipGetErrorString(le)));
+    }
     // the raw slot is free once the conversion has run: released after an event of the copy stream
-    HIP_TRY(hipEventRecord(v->pend_copied, v->copy_stream));
+    {
+        const hipError_t ee = hipEventRecord(v->pend_copied, v->copy_stream);
+        if (ee != hipSuccess) return give_back(fail(TSDF_ERR_HIP, "hipEventRecord: %s", hipGetErrorString(ee)));
+    }
     tsdf_store::slots_release_after(v->store, &v->store->frames, &raw_slot, 1, &v->pend_copied, v);
+    raw_slot = -1;
     if (defer) {
         Collected c;
         c.slot = slot; c.mask_slot = -1; c.dev = static_cast<float *>(dev); c.mask = nullptr;
         return pool_slot_commit(v, c, cam2world);
     }
-    HIP_TRY(hipStreamWaitEvent(v->stream, v->pend_copied, 0));
+    {
+        const hipError_t we = hipStreamWaitEvent(v->stream, v->pend_copied, 0);
+        if (we != hipSuccess) return give_back(fail(TSDF_ERR_HIP, "hipStreamWaitEvent: %s", hipGetErrorString(we)));
+    }
     float c2b[16];
     compose_cam2base(v, cam2world, c2b);
     rc = launch_integrate(v, static_cast<const float *>(dev), nullptr, c2b);
-    if (rc) return rc;
+    if (rc) return give_back(rc);
     return stage_end(v, &slot, 1);
 }
 
@@ -2007,7 +2064,7 @@ int tsdf_integrate_rgbd(tsdf_volume *v, const float *depth_host, const uint8_t *
     std::memcpy(v->h_rgb[s], rgb_host, px * 3);           // the caller may free both images after we return
     int slot = -1;
     void *dev = nullptr;
-    rc = stage_begin(v, img, [&](float *pinned) { std::memcpy(pinned, depth_host, img); }, &slot, &dev);
+    rc = stage_begin(v, img, [&](float *pinned) { tsdf_host::copy_to_pinned(pinned, depth_host, img); }, &slot, &dev);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(v->d_rgb[s], v->h_rgb[s], px * 3, hipMemcpyHostToDevice, v->copy_stream));
     rc = stream_waits_for_copies(v);

@@ -114,19 +114,20 @@ TSDF::~TSDF()
 {
 	if (vol_ || grp_) {
 		if (save_on_destroy_) {
-			bool have = true;
+			// The mirrors are the reference's public members, refreshed here as it does (ref: src/tsdf.cu:101-104); the two files
+			// do not depend on them -- the writers stream device memory to the file through pinned staging pieces -- so a grid whose
+			// 2 x n host floats cannot be allocated, or whose download fails, still gets the files its destructor exists to write.
 			try {
-				if (download_mirrors() != TSDF_OK) { have = false; fail_in_destructor("tsdf_download", __LINE__); }  // ref: src/tsdf.cu:101-104
+				if (download_mirrors() != TSDF_OK) fail_in_destructor("tsdf_download", __LINE__);
 			} catch (const std::bad_alloc &) {   // the lazily allocated mirrors of a large grid
-				have = false;
-				std::cerr << "TSDF::~TSDF: out of host memory for the mirrors" << std::endl;
+				std::cerr << "TSDF::~TSDF: out of host memory for the mirrors (the files are written all the same)" << std::endl;
 			}
 			// ref: src/tsdf.cu:109-112 -- surface points, weight threshold 0.9 (tsdf_thresh 1.2 is unused there)
 			std::string name = "tsdf" + std::to_string(cfg_.id) + ".ply";
-			if (have && (grp_ ? tsdf_group_save_ply(grp_, name.c_str(), 0.9f) : tsdf_save_ply(vol_, name.c_str(), 0.9f)) != TSDF_OK)
+			if ((grp_ ? tsdf_group_save_ply(grp_, name.c_str(), 0.9f) : tsdf_save_ply(vol_, name.c_str(), 0.9f)) != TSDF_OK)
 				fail_in_destructor("tsdf_save_ply", __LINE__);
 			name = "tsdf" + std::to_string(cfg_.id) + ".bin";  // ref: src/tsdf.cu:116-132
-			if (have && (grp_ ? tsdf_group_save_bin(grp_, name.c_str()) : tsdf_save_bin(vol_, name.c_str())) != TSDF_OK)
+			if ((grp_ ? tsdf_group_save_bin(grp_, name.c_str()) : tsdf_save_bin(vol_, name.c_str())) != TSDF_OK)
 				fail_in_destructor("tsdf_save_bin", __LINE__);
 		}
 		if (grp_) tsdf_group_destroy(grp_);

@@ -272,7 +272,7 @@ int tsdf_group_integrate(tsdf_group *g, const float *depth_host, const float cam
         const size_t px = (size_t)g->cfg.im_height * g->cfg.im_width, bytes = px * sizeof(float);
         if (!g->h_pool) HIP_TRY(hipHostMalloc((void **)&g->h_pool, (size_t)tsdfk::kMaxFramesPerLaunch * bytes, hipHostMallocPortable));
         if (g->pend_count == 0) { int rc = group_wait_pool(g); if (rc) return rc; }
-        std::memcpy(g->h_pool + (size_t)g->pend_count * px, depth_host, bytes);
+        tsdf_host::copy_to_pinned(g->h_pool + (size_t)g->pend_count * px, depth_host, bytes);
         std::memcpy(g->pend_poses + 16 * g->pend_count, cam2world, 16 * sizeof(float));
         if (++g->pend_count >= std::min(g->defer_n, (int)tsdfk::kMaxFramesPerLaunch)) return group_flush(g);
         return TSDF_OK;
@@ -288,7 +288,7 @@ int tsdf_group_integrate(tsdf_group *g, const float *depth_host, const float cam
             HIP_TRY(hipEventSynchronize(g->ring_copied[(size_t)s * n + i]));
         }
     }
-    std::memcpy(g->h_ring[s], depth_host, img);          // the caller may free depth_host after we return
+    tsdf_host::copy_to_pinned(g->h_ring[s], depth_host, img);          // the caller may free depth_host after we return
     for (size_t i = 0; i < n; ++i) {
         tsdf_volume *v = g->slabs[i];
         int rc0 = bind_device(v);      // device current; frames given to a borrowed slab handle come first
@@ -327,7 +327,7 @@ int tsdf_group_integrate_frames(tsdf_group *g, const float *const *depth_host, c
         const int n = std::min(fpl, n_frames - k);
         rc = group_wait_pool(g);     // the pool is reused per pass
         if (rc) return rc;
-        for (int f = 0; f < n; ++f) std::memcpy(g->h_pool + (size_t)f * px, depth_host[k + f], img);
+        for (int f = 0; f < n; ++f) tsdf_host::copy_to_pinned(g->h_pool + (size_t)f * px, depth_host[k + f], img);
         rc = group_pass_from_pool(g, cam2world + 16 * (size_t)k, n);
         if (rc) return rc;
     }

@@ -346,9 +346,10 @@ __device__ __forceinline__ void class_pose_store(ClassPoseTable *t, const int f,
 // Why the claims are exact: the patch is planar and, when all corners are in front of the
 // camera, projects into the convex hull of its projected corners; camera-frame z is affine over it, so its
 // extremes are at the corners.  The corners are projected with ordinary fp32 arithmetic; the widening of the
-// pixel box (px_margin: 1.5 px + the host's bound on that arithmetic's and the per-voxel path's error, valid for
-// cz >= cz_short) and cz_pad on the z bounds (twice the host's error bound on cz) cover the difference to the exact
-// per-voxel values, and rounding is monotone: d - cz >= trunc in the reals implies RN(d - cz) >= trunc.  A NaN or an
+// pixel box (px_margin_u / _v, derived in host_derive.h, derive_projection_guards: 0.5 px -- a rounded pixel index is within
+// half a pixel of its u -- + the projection error of both paths, 3.2e-5 * (|f| + 4 (W + |c|)), valid for cz >= cz_short, +
+// 1/16 px for the roundings of u = f * q + c itself) and cz_pad on the z bounds (twice the host's error bound on cz) cover
+// the difference to the exact per-voxel values, and rounding is monotone: d - cz >= trunc in the reals implies RN(d - cz) >= trunc.  A NaN or an
 // infinity in the corner arithmetic fails a comparison and yields 0.
 // PAIRED: the two half-waves share the work on a box of slices -- lane l and lane l ^ 32 are given the same frame and
 // the same rectangle, the lower one slice gz (the box's near slice), the upper one slice gz1 (its far slice); each
@@ -540,6 +541,11 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
     // registers before, none of them now).  brick_shape_ok keeps a brick's span below 4 GiB.
     size_t brick_base = 0;
     unsigned int lane_byte = 0u;
+    // (BRICK) the lane's summary word as a 32-bit index, kept across the frame loop for the write-back instead of the three
+    // coordinates it is made from (with the row test below, which a one-row lane has already passed, this is what took the
+    // masked work-list kernel from 1 VGPR + 4 SGPRs spilled to none at its 64-register budget): a slab has one word per 256
+    // voxels, so the index fits while the slab holds fewer than 2^40 voxels (4 TB of volume: no device holds that)
+    uint32_t flag32 = 0u;
     constexpr bool kBuf = BRICK && !NT;
     __amdgpu_buffer_rsrc_t t_buf, w_buf;
     auto load_quad = [&](const bool tsdf, const int r) -> float4 {
@@ -584,6 +590,7 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
             w_buf = __builtin_amdgcn_make_buffer_rsrc(p.weight + brick_base, 0, -1, 0x00020000);
         }
         flag0 = brick_flag_index(gy0, xg);
+        flag32 = (uint32_t)flag0;
     } else if constexpr (FLAT) {
         const int chunk = b0 * 4 + threadIdx.y;
         const int q = chunk * 64 + threadIdx.x;
@@ -608,7 +615,7 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
     bool touched[R], tchanged[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        fl[r] = gy0 + r < p.dim_y ? p.flags[flag0 + (size_t)r * p.nseg] : 0u;
+        fl[r] = (R == 1 || gy0 + r < p.dim_y) ? p.flags[flag0 + (size_t)r * p.nseg] : 0u;
         ones[r] = (fl[r] & 1u) != 0u;
         t4[r] = make_float4(1.f, 1.f, 1.f, 1.f);
         w4[r] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -832,7 +839,7 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
             const bool front = all_front;   // the sign of cz over the whole patch (corner test)
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const bool row_ok = gy0 + r < p.dim_y;
+                const bool row_ok = R == 1 || gy0 + r < p.dim_y;   // R == 1: a lane whose row is outside has left above
                 const float dy = byv[r] - q.ty;
                 const v2f XY1 = {q.rx1 * dy, q.ry1 * dy};
                 const v2f XY2 = {x2, y2};
@@ -851,7 +858,7 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
         } else {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const bool row_ok = gy0 + r < p.dim_y;
+                const bool row_ok = R == 1 || gy0 + r < p.dim_y;   // R == 1: a lane whose row is outside has left above
                 const float dy = byv[r] - q.ty;
                 const float x1 = q.rx1 * dy, y1 = q.ry1 * dy;
 #pragma unroll
@@ -952,7 +959,7 @@ __device__ __forceinline__ void multi_body(const IntegrateParams &p, const Frame
         }
         if ((fl[r] & 1u) && !ones[r]) {
             if constexpr (BRICK) {
-                p.flags[brick_flag_index(gy0, xg)] = fl[r] & 2u;
+                p.flags[flag32] = fl[r] & 2u;
             } else {
                 p.flags[flag0 + (size_t)r * p.nseg] = fl[r] & 2u;
             }
@@ -1025,7 +1032,39 @@ struct BrickListParams {
     unsigned int bucket_cap;   // entries per sub-list: every brick of every super-brick it can receive
     ClassPoseTable *poses;     // the launch's frames for classify_patch, structure-of-arrays (written by the pre-pass)
     int nsx, nsy, nsz;         // super-bricks along x, y, z
+    // list_bucket: wedge_mode != 0 deals the super-bricks to the XCDs by image rows (see there); the base camera's position in
+    // voxel units relative to voxel (0, 0, z_begin) of the slab (rounded: the key only has to be the same on host and device),
+    // the super-brick's height and depth in voxels, the focal length in pixels (rounded)
+    int wedge_mode, wedge_oy, wedge_oz, super_h, super_d, fy_px;
 };
+
+// The sub-list (bucket) of super-brick `id` = (sx, sy, sz): workgroup j of integrate_brick_list takes its entries from sub-list
+// j % kListBuckets, and workgroups are dealt to the eight XCDs round robin by their index, so sub-list b is served by XCD b % 8.
+// wedge_mode 0 (what ships): a multiplicative hash of the index -- every sub-list, and with it every XCD, samples the whole
+// volume: the sub-lists run dry together, but every XCD's L2 ends up fetching every depth frame of the launch (32 x 1.2 MB; an
+// XCD has 4 MB).  wedge_mode 1 .. 3 (measurement build only, TSDF_WEDGE_MODE): the low three bits -- the XCD -- come from WHERE
+// the super-brick lies in the image: its centre's row under the base camera, in stripes of 16 (mode 3: 8) pixels dealt round
+// robin (a stripe is a wedge of the volume through the camera centre, so under any pose of the launch it projects onto a compact
+// part of the image); modes 2 and 3 rotate the stripe -> XCD map by three every four super-bricks along x, so that the image's top
+// and bottom rows -- where the bricks that straddle the border sit -- go round all XCDs.  Measured, round 4, same box, S-surf 512^3:
+// the Integrate kernel's measured traffic 908 -> 558 / 599 / 692 MB per launch (modes 1 / 2 / 3: the depth frames are no longer
+// fetched into all eight L2s) but 0.0256 -> 0.0305 / 0.0283 / 0.0276 ms per frame (4.5 - 5.0 resident wavefronts per SIMD instead
+// of 5.6: the XCDs' shares of the per-voxel work are no longer alike, and the launch is bound by instruction issue, not by
+// bytes); the fr3 trajectory 4.15 -> 3.82 GB, 0.1498 -> 0.1507.  Integer arithmetic only: the host counts the sub-lists'
+// capacities with the same function.
+__host__ __device__ inline unsigned int list_bucket(const unsigned int id, const int sx, const int sy, const int sz, const BrickListParams &bl)
+{
+    const unsigned int h = id * 2654435761u;
+    if (bl.wedge_mode == 0) return h >> 26;
+    const int yc = bl.wedge_oy + (2 * sy + 1) * bl.super_h / 2;
+    int zc = bl.wedge_oz + (2 * sz + 1) * bl.super_d / 2;
+    if (zc < 1) zc = 1;
+    int t = (yc * 256) / zc;                             // 256 * tan of the elevation; |yc| < 2^16
+    t = t > 65536 ? 65536 : (t < -65536 ? -65536 : t);   // (a tangent beyond 256 is outside any image; keeps the product below 2^31)
+    const int stripe = (t * bl.fy_px) >> (bl.wedge_mode == 3 ? 11 : 12);       // rows / 16 or / 8 (arithmetic shift: floor)
+    const int rot = bl.wedge_mode >= 2 ? 3 * (sx >> 2) : 0;
+    return ((h >> 29) << 3) | ((unsigned int)(stripe + rot) & 7u);
+}
 
 __global__ __launch_bounds__(256) void classify_brick_list(MultiParamsInline mp, BrickListParams bl)
 {
@@ -1055,8 +1094,8 @@ __global__ __launch_bounds__(256) void classify_brick_list(MultiParamsInline mp,
     // the sub-list of this super-brick: a multiplicative hash of its index, so that every sub-list samples the whole volume
     // (index mod 64 would be the slice group -- the sub-lists of slice groups in free space or behind the walls would run dry
     // long before the others and the launch would end on a quarter of its wavefronts)
-    static_assert(kListBuckets == 64, "the hash keeps the top six bits");
-    const unsigned int bkt = ((unsigned int)id * 2654435761u) >> 26;
+    static_assert(kListBuckets == 64, "six bits: list_bucket");
+    const unsigned int bkt = list_bucket((unsigned int)id, sx, sy, sz, bl);
     unsigned char *bucket = bl.counters + (size_t)bkt * kBucketStride;
     if (lane == 0) {
         // claims at super-brick granularity (what the per-launch decision is made from; the host adds the buckets up); the

@@ -87,6 +87,9 @@ def classify(tiles, umin, umax, vmin, vmax, czmin, czmax, mu, mv, W, H, trunc, p
     out[free] = 1
     out[skip & ~free] = 2
     out[miss] = 2
+    # 3 = "free wherever inside": the box straddles an image border, every pixel of its clipped pixel box is valid and at
+    # least trunc deeper than the farthest corner -- each voxel is updated with dist = 1 iff its pixel lies inside the image
+    out[(out == 0) & ~inside & (dmin >= czmax + pad + trunc)] = 3
     out[~ok] = 0
     return out
 
@@ -130,6 +133,7 @@ def main():
     und = {("brick", T): 0 for T in tile_sizes}
     und.update({("lane", T): 0 for T in tile_sizes})
     und_noband = dict(und)
+    border = {T: 0 for T in tile_sizes}              # bricks a "free wherever inside the image" claim would settle
     lane_und_count = {T: 0 for T in tile_sizes}     # undecided lanes in bricks the lane-level test leaves undecided
     for z0 in range(0, D, bz):
         zs = origin[2] + (z0 + np.arange(bz)) * vs - t[2]
@@ -173,11 +177,12 @@ def main():
               boxes(pcz, lshp, np.min), boxes(pcz, lshp, np.max)]
         for T in tile_sizes:
             cb = classify(tiles[T], *bb, mu, mv, W, H, trunc, pad, cz_short)
-            ub = cb == 0
+            border[T] += int((cb == 3).sum())
+            ub = (cb == 0) | (cb == 3)
             und[("brick", T)] += int(ub.sum())
             und_noband[("brick", T)] += int((ub & ~b_band).sum())
             cl = classify(tiles[T], *lb, mu, mv, W, H, trunc, pad, cz_short)        # [bz, D, D/4]
-            lane_und = (cl == 0).reshape(bz // bz, bz, D // by, by, D // bx, bx // 4)
+            lane_und = ((cl == 0) | (cl == 3)).reshape(bz // bz, bz, D // by, by, D // bx, bx // 4)
             n_und = lane_und.sum(axis=(1, 3, 5))
             ul = (n_und > 0) & ub                 # the lane-level test runs on the bricks their own box left undecided
             und[("lane", T)] += int(ul.sum())
@@ -188,6 +193,9 @@ def main():
     print(f"\nS-surf {D}^3 @ {vs * 1000:g} mm, frame {a.frame}, brick {bx}x{by}x{bz}, noise {a.noise_mm} mm, holes {a.holes}")
     print(f"bricks {n}: with a band voxel {tot['band']} ({100 * tot['band'] / n:.2f} %), nothing updated {100 * tot['none'] / n:.2f} %, "
           f"all dist=1 {100 * tot['free'] / n:.2f} %, mixed without band {100 * tot['mixed'] / n:.2f} %")
+    for T in tile_sizes:
+        print(f"  of the undecided bricks, {T}-pixel tiles: {border[T]} ({100 * border[T] / n:.2f} % of the bricks) straddle an image border over "
+              "valid far pixels only (\"free wherever inside the image\")")
     for key in und:
         lvl, T = key
         extra = f", {lane_und_count[T] / max(und[key], 1):.1f} undecided lanes per such brick" if lvl == "lane" else ""
