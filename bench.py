@@ -796,7 +796,8 @@ def main():
         kname, kname_source = PMC_KERNEL_NAMES[ksub], "rocprofv3 Kernel_Name of this run's PMC passes"
 
     mode_desc = ("one kernel launch per step (tsdf_integrate_device per frame: the reference's TSDF::Integrate call shape)" if fpl == 1
-                 else f"tsdf_integrate_frames_device, up to {fpl} frames per pass over the volume")
+                 else f"tsdf_integrate_frames{'_labels' if args.labels > 0 else ''}_device, up to {fpl} frames per pass over the volume"
+                      + (f", per-voxel label fusion from {args.labels} instance masks per frame in the same passes" if args.labels > 0 else ""))
     line = {
         # BASELINE.json's metric, naming the grid that was integrated (N = 1: its 512³; N > 1: configs[3]'s 1024³ by default)
         "metric": f"Mvoxels/sec integrated, {grid_label(dims)} grid @ 640×480 depth; achieved HBM GB/s %peak",
@@ -816,7 +817,8 @@ def main():
                                 + ("" if part_world == 1 else
                                    f"; strong scaling: the {dims[0]}x{dims[1]}x{dims[2]} @ {vs * 1000:g} mm grid"
                                    + (" of BASELINE.json configs[3]" if dims == (1024, 1024, 1024) and abs(vs - 0.002) < 1e-9 else "")
-                                   + f" is the same at every N > 1 (at N = 8 a slab holds the 134 M voxels of the N = 1 line's 512^3 grid)"
+                                   + " is the same at every N > 1"
+                                   + (" (at N = 8 a slab holds the 134 M voxels of the N = 1 line's 512^3 grid)" if dims == (1024, 1024, 1024) else "")
                                    if scaling == "strong" else
                                    f"; weak scaling: every rank's slab holds the {D}^3 voxels of the N = 1 grid, the global grid grows with N")
                                 + (f"; single-GPU rehearsal of rank {args.emulate_rank} of {part_world} (value = this slab's rate)"

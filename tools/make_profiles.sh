@@ -1,8 +1,8 @@
 #!/bin/bash
 # Everything under profiles/<round>_* comes from ONE call of this script on the GPU box:
-#   bash tools/make_profiles.sh r03        (then copy gpurun_out/<round>/* into profiles/)
+#   bash tools/make_profiles.sh r04        (then copy gpurun_out/<round>/* into profiles/)
 set -o pipefail
-R=${1:-r03}
+R=${1:-r04}
 out=$GRAFT_REPO_ROOT/gpurun_out/$R
 mkdir -p $out
 export TMPDIR=/tmp
@@ -14,12 +14,23 @@ stats() {   # stats <tag> <bench args...>: rocprofv3 --kernel-trace --stats of t
   cp $(find $out/_kt_$tag -name "*kernel_stats.csv" | head -1) $out/${R}_${tag}_kernel_stats.csv
   rm -rf $out/_kt_$tag $out/_kt_$tag.err
 }
-stats sband512 && stats ssurf512 --workload ssurf && stats traj1024 --workload traj && stats ssurf200 --workload ssurf --grid 200 || exit 1
+CFG4="--workload ssurf --grid 2048 --voxel-mm 2 --emulate-world 8 --labels 6"     # BASELINE.json configs[4] as one rank sees it
+stats sband512 && stats ssurf512 --workload ssurf && stats traj1024 --workload traj && stats ssurf200 --workload ssurf --grid 200 \
+  && stats cfg4_slab2048_labels_rank1 $CFG4 --emulate-rank 1 || exit 1
 cd $GRAFT_REPO_ROOT
 # the driver's command, as the driver runs it (in-run PMC traffic, companion legs, CPU baseline)
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/${R}_bench_default.json 2> $out/_bench.err || exit 1
 python3 bench.py --workload ssurf > $out/${R}_bench_ssurf512.json 2>> $out/_bench.err || exit 1
 python3 bench.py --workload traj > $out/${R}_bench_traj1024.json 2>> $out/_bench.err || exit 1
+# BASELINE.json configs[4]: one rank's 2048 x 2048 x 256 slab of the 2048^3 @ 2 mm grid with per-voxel label fusion (ranks 1 and 2:
+# the slab with the sphere's visible cap, and the one behind it), measured bytes and issue-slot share in the line
+for r in 1 2; do
+  python3 bench.py $CFG4 --emulate-rank $r --no-cpu-baseline > $out/${R}_bench_cfg4_slab2048_labels_rank$r.json 2>> $out/_bench.err || exit 1
+done
+# the N > 1 line on the one GPU there is: one rank's slab of configs[3] (1024^3 @ 2 mm cut eight ways), and the whole N-rank code
+# path over RCCL with one rank (process group, fences, strong_512 / n1_same_job legs, halo step, extraction)
+python3 bench.py --emulate-world 8 --emulate-rank 3 --steps 20 --warmup 5 --no-cpu-baseline > $out/${R}_bench_configs3_rank3_of_8.json 2>> $out/_bench.err || exit 1
+python3 bench.py --dist-world1 --steps 20 --warmup 5 --no-extras --strong-leg --no-traffic --no-cpu-baseline > $out/${R}_bench_dist_world1_rccl.json 2>> $out/_bench.err || exit 1
 # SQ counters of the Integrate kernel of the classified fused launches and of the per-voxel fused kernel in the band
 for t in "ssurf512 --workload ssurf" "traj1024 --workload traj" "sband512_fused --workload sband --mode fused"; do
   set -- $t; tag=$1; shift
@@ -30,7 +41,16 @@ done
 ( bash tools/pmc_bytes.sh ${R}_cal_bricks integrate_brick_list --workload sfull --mode fused --variant 8
   bash tools/pmc_bytes.sh ${R}_cal_rows integrate_multi_inline --workload sfull --mode fused --variant 7 ) > $out/${R}_pmc_calibration_sfull512.txt 2>&1
 python3 tools/batch_time.py --n 16 > $out/${R}_batch_time_16x200.txt 2>&1
-python3 tools/host_path_time.py > $out/${R}_host_path_time.txt 2>&1
+( python3 tools/host_path_time.py
+  g++ -O2 -o /tmp/host_copy tools/microbench/host_copy.cpp && /tmp/host_copy ) > $out/${R}_host_path_time.txt 2>&1
+# where the brick work list's extra traffic comes from: the sub-lists dealt to the XCDs by image-row wedges (measurement build)
+if [ -f semantic_slam_amd/libtsdf_hip_exp.so ]; then
+  for m in 0 1 2 3 0; do
+    TSDF_HIP_LIB=$PWD/semantic_slam_amd/libtsdf_hip_exp.so TSDF_WEDGE_MODE=$m python3 bench.py --workload ssurf --no-extras --no-cpu-baseline 2>> $out/_bench.err | python3 -c "
+import sys, json; d = json.loads(sys.stdin.read().strip()); r = d['roofline']; v = r.get('valu') or {}
+print('S-surf 512^3, list_bucket mode $m: %.5f ms per frame, measured traffic %.1f MB per launch (%.2f x algorithmic), %.2f wavefronts per SIMD, issue-slot share %.3f' % (d['ms_per_step'], (r['traffic'] or 0) / 1e6, r.get('traffic_over_algorithmic') or 0, v.get('mean_waves_per_simd') or 0, v.get('valu_issue_frac') or 0))"
+  done > $out/${R}_wedge_modes.txt 2>&1
+fi
 python3 tools/claim_rate.py --workload ssurf --shapes 2,4,8 > $out/${R}_claim_rate.txt 2>&1
 python3 tools/claim_rate.py --workload traj --grid 1024 --shapes 2,4,8 >> $out/${R}_claim_rate.txt 2>&1
 rm -f $out/_bench.err
