@@ -8,6 +8,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #if defined(__x86_64__)
 #include <immintrin.h>
@@ -45,6 +46,10 @@ inline void copy_to_pinned(void *dst, const void *src, size_t n)
 {
 #if defined(__x86_64__)
     static const bool avx2 = __builtin_cpu_supports("avx2");
+#ifdef TSDF_EXPERIMENTS
+    static const bool plain = std::getenv("TSDF_PLAIN_MEMCPY") != nullptr;      // A/B knob of the measurement build
+    if (plain) { std::memcpy(dst, src, n); return; }
+#endif
     if (avx2 && n >= 65536) { copy_streaming_avx2(dst, src, n); return; }
 #endif
     std::memcpy(dst, src, n);

@@ -143,6 +143,7 @@ struct tsdf_volume {
     bool flat;             // dim_x % 256 != 0: summary-maintaining launches use the flat mapping
     int brick_q, brick_r, brick_s;   // wavefront brick of the classified launches (choose_brick / tsdf_set_brick_shape); q = 0: none
     int tile;                        // pixels per edge of the depth tiles of this handle's classified launches (tile_edge_for)
+    bool fine_tables = false;        // ... and, beside them, 4-pixel tiles for brick-sized boxes (fine_tables_for)
     bool flags_known_zero;
     unsigned int *d_super;       // per super-brick frame words of the current fused brick launch (classify_superbricks)
     size_t super_words;
@@ -349,6 +350,9 @@ tsdfk::IntegrateParams make_params(const tsdf_volume *v, const float *depth_dev,
     p.tiles_w = (c.im_width + v->tile - 1) / v->tile;
     p.tiles_h = (c.im_height + v->tile - 1) / v->tile;
     p.tile_inv = 1.0f / (float)v->tile;
+    p.fine = nullptr;                // set by the launch that builds the fine tables
+    p.fine_w = v->fine_tables ? (c.im_width + tsdfk::kFineTile - 1) / tsdfk::kFineTile : 0;
+    p.fine_h = v->fine_tables ? (c.im_height + tsdfk::kFineTile - 1) / tsdfk::kFineTile : 0;
     p.px_margin_u = g.px_margin_u; p.px_margin_v = g.px_margin_v;
     p.shortcut_stats = v->d_shortcut_stats;
     p.claim_counter = nullptr;
@@ -392,6 +396,19 @@ int tile_edge_for(const tsdf_config &c)
     const int64_t n = (int64_t)c.dim_x * c.dim_y * (int64_t)(c.z_end - c.z_begin);
     const int64_t fine_tiles = (int64_t)((c.im_width + 7) / 8) * ((c.im_height + 7) / 8);
     return (!g_create_for_batch && n >= kFineTileMinVoxels && fine_tiles <= tsdfk::kTileLdsEntries) ? 8 : 16;
+}
+
+// Fine (4-pixel) tiles beside the 8-pixel tables: where a fused launch is long enough to repay two more small table kernels and
+// 1.4 MB more table per frame (tsdf_multiframe.hip.h, fine_tile_levels).
+constexpr int64_t kFineLevelMinVoxels = 64000000;      // measured: 512^3 S-surf 0.0255 -> 0.0240 ms per frame, 320^3 0.0102 -> 0.0105
+bool fine_tables_for(const tsdf_config &c, int tile)
+{
+    const int64_t n = (int64_t)c.dim_x * c.dim_y * (int64_t)(c.z_end - c.z_begin);
+    bool on = tile == 8 && n >= kFineLevelMinVoxels;
+#ifdef TSDF_EXPERIMENTS
+    if (const char *e = std::getenv("TSDF_FINE_TILES")) on = tile == 8 && std::atoi(e) != 0;     // A/B knob of the measurement build
+#endif
+    return on;
 }
 
 // One-frame masked launches are classified per workgroup when the launch is large enough to repay the three small
@@ -703,6 +720,22 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
         if (rc) return rc;
         rc = build_tile_tables(v->stream, c, mi.common, depth_dev, masks_dev, n, tiles, v->d_claims);
         if (rc) return rc;
+        if (v->fine_tables) {
+            // the fine tables of the launch's frames, behind its kMaxFramesPerLaunch coarse ones in the same slot
+            float2 *fine = tiles + (size_t)tsdfk::kMaxFramesPerLaunch * per_frame;
+            tsdfk::FineTileParams fp;
+            for (int f = 0; f < tsdfk::kMaxFramesPerLaunch; ++f) {
+                fp.depth[f] = depth_dev[f < n ? f : 0];
+                fp.mask[f] = masks_dev ? masks_dev[f < n ? f : 0] : nullptr;
+            }
+            fp.fine = fine;
+            fp.H = c.im_height; fp.W = c.im_width; fp.fw = mi.common.fine_w; fp.fh = mi.common.fine_h;
+            fp.max_depth = c.max_depth;
+            hipLaunchKernelGGL(tsdfk::fine_tile_base, dim3((unsigned)((fp.fw + 63) / 64), (unsigned)fp.fh, (unsigned)n), dim3(64), 0, v->stream, fp);
+            hipLaunchKernelGGL(tsdfk::fine_tile_levels, dim3((unsigned)((fp.fw * fp.fh + 255) / 256), (unsigned)n), dim3(256), 0, v->stream, fine, fp.fw, fp.fh);
+            HIP_TRY(hipGetLastError());
+            mi.common.fine = fine;
+        }
         for (int f = 0; f < n; ++f) mi.frames[f].tiles = tiles + (size_t)f * per_frame;
         for (int f = n; f < tsdfk::kMaxFramesPerLaunch; ++f) mi.frames[f] = mi.frames[0];
     }
@@ -1206,9 +1239,13 @@ int tsdf_create(const tsdf_config *cfg, tsdf_volume **out)
     // staging, deferral and tile-table memory: the store shared by every handle of this device and image size (nothing is
     // allocated until a frame arrives)
     v->tile = tile_edge_for(*cfg);
+    v->fine_tables = fine_tables_for(*cfg, v->tile);
     {
         const int tw = (cfg->im_width + v->tile - 1) / v->tile, th = (cfg->im_height + v->tile - 1) / v->tile;
-        const size_t table_bytes = (int64_t)tw * th <= 16384 ? tsdfk::kMaxFramesPerLaunch * tile_table_elems_host(tw, th) * sizeof(float2) : 0;
+        const int fw = (cfg->im_width + tsdfk::kFineTile - 1) / tsdfk::kFineTile, fh = (cfg->im_height + tsdfk::kFineTile - 1) / tsdfk::kFineTile;
+        // a launch's tables: kMaxFramesPerLaunch coarse sparse tables, then (fine_tables) as many fine ones
+        const size_t table_bytes = (int64_t)tw * th <= 16384
+            ? tsdfk::kMaxFramesPerLaunch * (tile_table_elems_host(tw, th) + (v->fine_tables ? tsdfk::fine_table_elems(fw, fh) : 0)) * sizeof(float2) : 0;
         if ((e = tsdf_store::store_ref(cfg->device, (size_t)cfg->im_height * cfg->im_width, table_bytes, &v->store)) != hipSuccess ||
             (e = hipEventCreateWithFlags(&v->flush_done[0], hipEventDisableTiming)) != hipSuccess ||
             (e = hipEventCreateWithFlags(&v->flush_done[1], hipEventDisableTiming)) != hipSuccess ||
@@ -1799,6 +1836,32 @@ int tsdf_selftest_tile_tables(int32_t device, const float *depth_dev, const uint
         (void)hipFree(d_a);
         (void)hipFree(d_b);
         if (e != hipSuccess) return fail(TSDF_ERR_HIP, "tsdf_selftest_tile_tables: %s", hipGetErrorString(e));
+        for (size_t i = 0; i < per; ++i) bad += std::memcmp(&a[i], &b[i], sizeof(float2)) != 0;
+    }
+    {   // the fine table (4-pixel tiles, nine levels): the two kernels the library launches against the pixel-by-pixel one
+        const int fw = (im_width + tsdfk::kFineTile - 1) / tsdfk::kFineTile, fh = (im_height + tsdfk::kFineTile - 1) / tsdfk::kFineTile;
+        const size_t per = tsdfk::fine_table_elems(fw, fh);
+        float2 *d_a = nullptr, *d_b = nullptr;
+        HIP_TRY(hipMalloc((void **)&d_a, per * sizeof(float2)));
+        if (hipMalloc((void **)&d_b, per * sizeof(float2)) != hipSuccess) { (void)hipFree(d_a); return fail(TSDF_ERR_HIP, "tsdf_selftest_tile_tables: hipMalloc"); }
+        (void)hipMemset(d_a, 0xff, per * sizeof(float2));
+        (void)hipMemset(d_b, 0x7f, per * sizeof(float2));
+        tsdfk::FineTileParams fp;
+        for (int f = 0; f < tsdfk::kMaxFramesPerLaunch; ++f) { fp.depth[f] = depth_dev; fp.mask[f] = mask_dev; }
+        fp.H = im_height; fp.W = im_width; fp.fw = fw; fp.fh = fh; fp.max_depth = max_depth;
+        fp.fine = d_a;
+        hipLaunchKernelGGL(tsdfk::fine_tile_base, dim3((unsigned)((fw + 63) / 64), (unsigned)fh, 1), dim3(64), 0, 0, fp);
+        hipLaunchKernelGGL(tsdfk::fine_tile_levels, dim3((unsigned)((fw * fh + 255) / 256), 1), dim3(256), 0, 0, d_a, fw, fh);
+        fp.fine = d_b;
+        hipLaunchKernelGGL(tsdfk::fine_table_reference, dim3((unsigned)((per + 255) / 256), 1), dim3(256), 0, 0, fp);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        std::vector<float2> a(per), b(per);
+        if (e == hipSuccess) e = hipMemcpy(a.data(), d_a, per * sizeof(float2), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(b.data(), d_b, per * sizeof(float2), hipMemcpyDeviceToHost);
+        (void)hipFree(d_a);
+        (void)hipFree(d_b);
+        if (e != hipSuccess) return fail(TSDF_ERR_HIP, "tsdf_selftest_tile_tables (fine): %s", hipGetErrorString(e));
         for (size_t i = 0; i < per; ++i) bad += std::memcmp(&a[i], &b[i], sizeof(float2)) != 0;
     }
     *mismatches = bad;

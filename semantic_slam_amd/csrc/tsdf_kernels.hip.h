@@ -75,6 +75,10 @@ struct IntegrateParams {
     // skipped by every frame} (tsdf_brick_list_stats).
     int tiles_w, tiles_h;
     float tile_inv;           // 1 / (pixels per tile edge): 1/16, or 1/8 for slabs large enough to repay the finer tables
+    // Fine tables (tsdf_multiframe.hip.h, fine_tile_levels): tiles of kFineTile x kFineTile pixels with the nine levels (2^ky x 2^kx
+    // tiles, ky, kx <= 2) a brick-sized box needs; frame f of the launch at fine + f * 9 * fine_w * fine_h.  Null = none.
+    const float2 *fine = nullptr;
+    int fine_w = 0, fine_h = 0;
     float px_margin_u, px_margin_v;
     unsigned int *shortcut_stats;
     float cz_short, cz_pad;   // per pose; copied into FramePose (see there)

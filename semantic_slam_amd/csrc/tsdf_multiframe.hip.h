@@ -291,6 +291,147 @@ __global__ __launch_bounds__(1024) void tile_sparse_table(float2 *tables, int tw
     }
 }
 
+// ---- fine tiles for brick-sized boxes (round 4) ------------------------------------------------------------------------------
+// A wavefront brick of 8 x 4 x 8 voxels projects onto 5 - 25 pixels, about the size of ONE 8-pixel tile, so the depth range
+// the sparse table returns for it is that of the two or three tiles its box touches: on a slanted surface several centimetres
+// more than the depths under the brick itself.  tools/claim_sim.py (the claim rule replayed on the CPU, S-surf 512^3): with
+// 8-pixel tiles 10.3 % of the bricks stay undecided per frame, with 4-pixel tiles 8.5 % (with per-pixel bounds 7.3 %; 1.5 %
+// hold a voxel of the truncation band).  A full sparse table over 4-pixel tiles would be 8.6 MB per frame; a brick-sized box
+// only ever spans a few of them, so the fine table holds just the nine levels (2^ky x 2^kx tiles, ky, kx <= 2: boxes of up to
+// 7 x 7 tiles = 28 pixels; 1.4 MB per 640 x 480 frame) and classify_patch falls back to the coarse table for larger boxes (the
+// super-bricks of the pre-pass, bricks close to the camera).  Same tile semantics as the coarse table (see the top of this file):
+// x = smallest depth if every pixel passes the reference's range test else -inf, y = largest passing depth or -inf, a NaN
+// poisons its tile to (-inf, +inf); levels combine by min / max -- exact and order-free, so any evaluation order gives the
+// table fine_table_reference computes pixel by pixel (tsdf_selftest_tile_tables compares them bit for bit).
+constexpr int kFineTile = 4;
+constexpr int kFineLevels = 3;                       // per axis: 1, 2, 4 tiles
+__host__ __device__ inline size_t fine_table_elems(int fw, int fh) { return (size_t)kFineLevels * kFineLevels * fw * fh; }
+
+struct FineTileParams {
+    const float *depth[kMaxFramesPerLaunch];
+    const uint8_t *mask[kMaxFramesPerLaunch];
+    float2 *fine;           // n_frames tables of fine_table_elems(fw, fh)
+    int H, W, fw, fh;
+    float max_depth;
+};
+
+// Level (0, 0): one thread per tile, four rows of four pixels (consecutive threads read consecutive 16-byte pieces of a row).
+// grid = (ceil(fw / 64), fh, frames), block = 64.
+__global__ __launch_bounds__(64) void fine_tile_base(FineTileParams tp)
+{
+    const int tx = blockIdx.x * 64 + threadIdx.x, ty = blockIdx.y, f = blockIdx.z;
+    if (tx >= tp.fw) return;
+    const float *d = tp.depth[f];
+    const uint8_t *m = tp.mask[f];
+    const float inf = __builtin_inff();
+    float mn = inf, mx = -inf;
+    bool all_valid = true, nan = false;
+    const int px0 = tx * kFineTile;
+    const bool vec = (tp.W & 3) == 0 && (reinterpret_cast<uintptr_t>(d) & 15) == 0 && (m == nullptr || (reinterpret_cast<uintptr_t>(m) & 3) == 0);
+#pragma unroll
+    for (int r = 0; r < kFineTile; ++r) {
+        const int py = ty * kFineTile + r;
+        if (py >= tp.H) continue;
+        const size_t at = (size_t)py * tp.W + px0;
+        float v[4];
+        bool in[4];
+        if (vec) {                // W % 4 == 0: the four pixels are inside the row together
+            const float4 q = *reinterpret_cast<const float4 *>(d + at);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+            in[0] = in[1] = in[2] = in[3] = true;
+            if (m != nullptr) {
+                const uchar4 k = *reinterpret_cast<const uchar4 *>(m + at);
+                v[0] = v[0] * (k.x >= 128 ? 1.0f : 0.0f); v[1] = v[1] * (k.y >= 128 ? 1.0f : 0.0f);   // inf * 0 = NaN, as in the kernel
+                v[2] = v[2] * (k.z >= 128 ? 1.0f : 0.0f); v[3] = v[3] * (k.w >= 128 ? 1.0f : 0.0f);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                in[j] = px0 + j < tp.W;
+                v[j] = in[j] ? d[at + j] : 0.0f;
+                if (in[j] && m != nullptr) v[j] = v[j] * (m[at + j] >= 128 ? 1.0f : 0.0f);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (!in[j]) continue;
+            nan |= v[j] != v[j];
+            const bool valid = (v[j] > 0.0f) & (v[j] <= tp.max_depth);
+            all_valid &= valid;
+            if (valid) { mn = fminf(mn, v[j]); mx = fmaxf(mx, v[j]); }
+        }
+    }
+    float2 out;
+    out.x = (all_valid && !nan) ? mn : -inf;
+    out.y = nan ? inf : mx;
+    tp.fine[(size_t)f * fine_table_elems(tp.fw, tp.fh) + (size_t)ty * tp.fw + tx] = out;
+}
+
+// Levels (ky, kx) != (0, 0) from level (0, 0): one thread per tile position reads the up to 4 x 4 base tiles that start there
+// (clipped at the table's edge, as the coarse table's levels are) and writes its eight combinations.
+// grid = (ceil(fw * fh / 256), frames), block = 256.
+__global__ __launch_bounds__(256) void fine_tile_levels(float2 *fine, int fw, int fh)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x, n = fw * fh;
+    if (k >= n) return;
+    float2 *T = fine + (size_t)blockIdx.y * fine_table_elems(fw, fh);
+    const int ty = k / fw, tx = k - ty * fw;
+    const float inf = __builtin_inff();
+    float2 b[4][4];
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx)
+            b[dy][dx] = (ty + dy < fh && tx + dx < fw) ? T[(size_t)(ty + dy) * fw + tx + dx] : make_float2(inf, -inf);   // neutral
+    // rows first: r[dy][kx] = combination of b[dy][0 .. 2^kx - 1]
+    float2 r[4][kFineLevels];
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy) {
+        r[dy][0] = b[dy][0];
+        r[dy][1] = make_float2(fminf(b[dy][0].x, b[dy][1].x), fmaxf(b[dy][0].y, b[dy][1].y));
+        const float2 hi = make_float2(fminf(b[dy][2].x, b[dy][3].x), fmaxf(b[dy][2].y, b[dy][3].y));
+        r[dy][2] = make_float2(fminf(r[dy][1].x, hi.x), fmaxf(r[dy][1].y, hi.y));
+    }
+#pragma unroll
+    for (int kx = 0; kx < kFineLevels; ++kx) {
+        const float2 c0 = r[0][kx];
+        const float2 c1 = make_float2(fminf(r[0][kx].x, r[1][kx].x), fmaxf(r[0][kx].y, r[1][kx].y));
+        const float2 h2 = make_float2(fminf(r[2][kx].x, r[3][kx].x), fmaxf(r[2][kx].y, r[3][kx].y));
+        const float2 c2 = make_float2(fminf(c1.x, h2.x), fmaxf(c1.y, h2.y));
+        if (kx > 0) T[(size_t)(0 * kFineLevels + kx) * n + k] = c0;
+        T[(size_t)(1 * kFineLevels + kx) * n + k] = c1;
+        T[(size_t)(2 * kFineLevels + kx) * n + k] = c2;
+    }
+}
+
+// The same table pixel by pixel (self-test only): one thread per (level, tile position).
+__global__ __launch_bounds__(256) void fine_table_reference(FineTileParams tp)
+{
+    const int n = tp.fw * tp.fh;
+    const int id = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
+    if (id >= kFineLevels * kFineLevels * n) return;
+    const int level = id / n, k = id - level * n, ky = level / kFineLevels, kx = level - ky * kFineLevels;
+    const int ty = k / tp.fw, tx = k - ty * tp.fw;
+    const int x0 = tx * kFineTile, x1 = min((tx + (1 << kx)) * kFineTile, tp.W), y0 = ty * kFineTile, y1 = min((ty + (1 << ky)) * kFineTile, tp.H);
+    const float inf = __builtin_inff();
+    float mn = inf, mx = -inf;
+    bool all_valid = true, nan = false;
+    for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) {
+            float v = tp.depth[f][(size_t)y * tp.W + x];
+            if (tp.mask[f] != nullptr) v = v * (tp.mask[f][(size_t)y * tp.W + x] >= 128 ? 1.0f : 0.0f);
+            nan |= v != v;
+            const bool valid = (v > 0.0f) & (v <= tp.max_depth);
+            all_valid &= valid;
+            if (valid) { mn = fminf(mn, v); mx = fmaxf(mx, v); }
+        }
+    // a NaN poisons only its own base tile to (-inf, +inf); min / max over the tiles of the block then give (-inf, +inf) too
+    float2 out;
+    out.x = (all_valid && !nan) ? mn : -inf;
+    out.y = nan ? inf : mx;
+    tp.fine[(size_t)f * fine_table_elems(tp.fw, tp.fh) + (size_t)level * n + k] = out;
+}
+
 // What classify_patch reads of a frame: 16 dwords, grouped as four 16-byte words so that the 32 frames of a launch can be kept
 // structure-of-arrays (ClassPoseTable: lane f reads word k of frame f at w[k][f], 512 contiguous bytes per wave instruction
 // instead of 64 lanes picking 72-byte blocks apart).
@@ -355,9 +496,13 @@ __device__ __forceinline__ void class_pose_store(ClassPoseTable *t, const int f,
 // the same rectangle, the lower one slice gz (the box's near slice), the upper one slice gz1 (its far slice); each
 // projects the four corners of its slice and the six extremes are combined across the halves (min and max are exact,
 // so the class is the one the eight-corner evaluation gives).  Every lane of the wavefront must make the call.
+// fine: the frame's fine table (fine_tile_levels) or null; consulted when the box spans at most 7 x 7 fine tiles, i.e. when the
+// four overlapping blocks of a level it holds cover the box -- the tiles then hug the box more closely than the coarse ones and
+// the same comparisons decide more often; any table of correct tile bounds gives a correct claim.
 template <bool PAIRED = false>
 __device__ __forceinline__ int classify_patch(const IntegrateParams &p, const ClassPose &q, const int xa,
-                                              const int xb, const int ya, const int yb, const int gz, const int gz1 = -1)
+                                              const int xb, const int ya, const int yb, const int gz, const int gz1 = -1,
+                                              const float2 *__restrict__ fine = nullptr)
 {
     if constexpr (!PAIRED) { if (q.tiles == nullptr) return 0; }
     const float dxa = (p.ox + (float)xa * p.vs) - q.tx, dxb = (p.ox + (float)xb * p.vs) - q.tx;
@@ -402,15 +547,25 @@ __device__ __forceinline__ int classify_patch(const IntegrateParams &p, const Cl
     const float wmax = (float)(p.W - 1), hmax = (float)(p.H - 1);
     if (!(u1 >= 0.0f) | !(v1 >= 0.0f) | !(u0 <= wmax) | !(v0 <= hmax)) return 2;   // the box misses the image
     const bool inside = (u0 >= 0.0f) & (v0 >= 0.0f) & (u1 <= wmax) & (v1 <= hmax);
-    const int tx0 = (int)(fmaxf(u0, 0.0f) * p.tile_inv), tx1 = (int)(fminf(u1, wmax) * p.tile_inv);     // tile_inv: a power of two, exact
-    const int ty0 = (int)(fmaxf(v0, 0.0f) * p.tile_inv), ty1 = (int)(fminf(v1, hmax) * p.tile_inv);
+    const float uc0 = fmaxf(u0, 0.0f), uc1 = fminf(u1, wmax), vc0 = fmaxf(v0, 0.0f), vc1 = fminf(v1, hmax);
+    int tx0 = (int)(uc0 * p.tile_inv), tx1 = (int)(uc1 * p.tile_inv);     // tile_inv: a power of two, exact
+    int ty0 = (int)(vc0 * p.tile_inv), ty1 = (int)(vc1 * p.tile_inv);
     // range query: four overlapping power-of-two blocks of level (ky, kx)
-    const int kx = 31 - __clz(tx1 - tx0 + 1), ky = 31 - __clz(ty1 - ty0 + 1);
-    const int n = p.tiles_w * p.tiles_h;
-    const float2 *L = q.tiles + (size_t)(ky * tile_levels(p.tiles_w) + kx) * n;
+    int kx = 31 - __clz(tx1 - tx0 + 1), ky = 31 - __clz(ty1 - ty0 + 1);
+    int tw = p.tiles_w;
+    const float2 *L = q.tiles + (size_t)(ky * tile_levels(p.tiles_w) + kx) * (p.tiles_w * p.tiles_h);
+    if (fine != nullptr) {
+        const float finv = 1.0f / (float)kFineTile;
+        const int fx0 = (int)(uc0 * finv), fx1 = (int)(uc1 * finv), fy0 = (int)(vc0 * finv), fy1 = (int)(vc1 * finv);
+        const int fkx = 31 - __clz(fx1 - fx0 + 1), fky = 31 - __clz(fy1 - fy0 + 1);
+        if (fkx < kFineLevels && fky < kFineLevels) {
+            tx0 = fx0; tx1 = fx1; ty0 = fy0; ty1 = fy1; kx = fkx; ky = fky; tw = p.fine_w;
+            L = fine + (size_t)(fky * kFineLevels + fkx) * (p.fine_w * p.fine_h);
+        }
+    }
     const int xb2 = tx1 - (1 << kx) + 1, yb2 = ty1 - (1 << ky) + 1;
-    const float2 a = L[ty0 * p.tiles_w + tx0], b = L[ty0 * p.tiles_w + xb2];
-    const float2 c = L[yb2 * p.tiles_w + tx0], d = L[yb2 * p.tiles_w + xb2];
+    const float2 a = L[ty0 * tw + tx0], b = L[ty0 * tw + xb2];
+    const float2 c = L[yb2 * tw + tx0], d = L[yb2 * tw + xb2];
     const float dmin = fminf(fminf(a.x, b.x), fminf(c.x, d.x));   // -inf unless every pixel of the box is valid
     const float dmax = fmaxf(fmaxf(a.y, b.y), fmaxf(c.y, d.y));   // the deepest valid pixel of the box
     const float thr_free = (czmax + q.cz_pad) + p.trunc;    // every pixel at least this deep: dist = 1 everywhere
@@ -1087,7 +1242,8 @@ __global__ __launch_bounds__(256) void classify_brick_list(MultiParamsInline mp,
     const ClassPose mine_q = class_pose(frames[lane & 31]);
     // the frames as integrate_brick_list's self-classifying wavefronts read them (the first wavefront of the launch writes)
     if (id == 0 && lane < kMaxFramesPerLaunch) class_pose_store(bl.poses, lane, mine_q);
-    const int cls = classify_patch<true>(p, mine_q, xa, xb, ya, yb, p.z_begin + z0, p.z_begin + z1);
+    const float2 *fine_f = p.fine != nullptr ? p.fine + (size_t)(lane & 31) * fine_table_elems(p.fine_w, p.fine_h) : nullptr;
+    const int cls = classify_patch<true>(p, mine_q, xa, xb, ya, yb, p.z_begin + z0, p.z_begin + z1, fine_f);
     const unsigned int super_free = (unsigned int)__ballot(cls == 1) & frames_mask;
     const unsigned int super_skip = (unsigned int)__ballot(cls == 2) & frames_mask;
     const int n_in = (i1 - i0 + 1) * (g1 - g0 + 1) * (zg1 - zg0 + 1);
@@ -1168,8 +1324,9 @@ __global__ __launch_bounds__(256, LABELS ? 6 : TSDF_BRICK_WAVES) void integrate_
         const int g = brick / p.bricks_per_group, i = brick - g * p.bricks_per_group;
         const int xa = i * p.brick_q * 4, ya = g * p.brick_r;
         const int z0 = zg * p.brick_s, z1 = min(z0 + p.brick_s - 1, p.nz - 1);
+        const float2 *fine_f = p.fine != nullptr ? p.fine + (size_t)(lane & 31) * fine_table_elems(p.fine_w, p.fine_h) : nullptr;
         const int cls = classify_patch<true>(p, class_pose(poses, lane & 31), xa, xa + p.brick_q * 4 - 1, ya, min(ya + p.brick_r - 1, p.dim_y - 1),
-                                             p.z_begin + z0, p.z_begin + z1);
+                                             p.z_begin + z0, p.z_begin + z1, fine_f);
         free_frames |= (unsigned int)__ballot(cls == 1) & frames_mask;
         skip_frames |= (unsigned int)__ballot(cls == 2) & frames_mask;
         free_frames = __builtin_amdgcn_readfirstlane(free_frames);

@@ -30,7 +30,7 @@ done
 # the N > 1 line on the one GPU there is: one rank's slab of configs[3] (1024^3 @ 2 mm cut eight ways), and the whole N-rank code
 # path over RCCL with one rank (process group, fences, strong_512 / n1_same_job legs, halo step, extraction)
 python3 bench.py --emulate-world 8 --emulate-rank 3 --steps 20 --warmup 5 --no-cpu-baseline > $out/${R}_bench_configs3_rank3_of_8.json 2>> $out/_bench.err || exit 1
-python3 bench.py --dist-world1 --steps 20 --warmup 5 --no-extras --strong-leg --no-traffic --no-cpu-baseline > $out/${R}_bench_dist_world1_rccl.json 2>> $out/_bench.err || exit 1
+python3 bench.py --dist-world1 --steps 20 --warmup 5 --no-extras --strong-leg --no-traffic --no-cpu-baseline 2>> $out/_bench.err | grep "^{" > $out/${R}_bench_dist_world1_rccl.json || exit 1     # (RCCL prints a version banner on stdout first)
 # SQ counters of the Integrate kernel of the classified fused launches and of the per-voxel fused kernel in the band
 for t in "ssurf512 --workload ssurf" "traj1024 --workload traj" "sband512_fused --workload sband --mode fused"; do
   set -- $t; tag=$1; shift
