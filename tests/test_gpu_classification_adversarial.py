@@ -227,7 +227,8 @@ def test_unaligned_frame_buffers(cuda, oracle):
     assert stats[(1, 1)] == stats[(0, 0)] == stats[(3, 2)] and stats[(0, 0)][1] > 0 and stats[(0, 0)][2] > 0, stats
 
 
-@pytest.mark.parametrize("nz,tiles", [(40, "8-pixel tiles (10.5 M voxels)"), (36, "16-pixel tiles (9.4 M voxels)")])
+@pytest.mark.parametrize("nz,tiles", [(40, "8-pixel tiles (10.5 M voxels)"), (36, "16-pixel tiles (9.4 M voxels)"),
+                                      (256, "8-pixel tables + 4-pixel fine tables (67 M voxels)")])
 def test_single_pixels_at_the_edges_of_projected_boxes(cuda, oracle, nz, tiles):
     """The pixel box of a brick's projected corners is widened by px_margin = 0.5625 + the projection error (csrc/tsdf_capi.hip):
     exactly what it takes to hold the rounded pixel of every voxel of the brick.  A margin that is too small shows where ONE
@@ -236,7 +237,8 @@ def test_single_pixels_at_the_edges_of_projected_boxes(cuda, oracle, nz, tiles):
     position relative to the tiles -- and the camera moves in steps of 0.13 pixel, with a slight roll, so that needles
     cross the edges of the projected boxes of all bricks along their rays.  A brick claimed "free" although one of its
     voxels rounds onto a needle gets dist = 1 where the reference writes a band value.  Every voxel of the 512 x 512 x nz
-    slab against the reference's own kernel (whole_volume.py); both tile sizes (the library picks 8 from 10 M voxels)."""
+    slab against the reference's own kernel (whole_volume.py); every table the library uses (8-pixel tiles from 10 M voxels, the
+    fine 4-pixel tables for brick-sized boxes from 64 M; 37 and 29 are coprime with 4 as well)."""
     import whole_volume as wv
     if not wv.available():
         pytest.skip("oracle/_ref/libtsdf_ref_hip.so not built")
@@ -269,9 +271,11 @@ def test_single_pixels_at_the_edges_of_projected_boxes(cuda, oracle, nz, tiles):
     wv.drop(f"needles{nz}")
 
 
+@pytest.mark.parametrize("nz", [40, 256])
 @pytest.mark.parametrize("edge", ["left", "right", "top", "bottom"])
-def test_image_border_with_fine_tiles(cuda, oracle, edge):
-    """test_patches_touching_the_image_border on a slab large enough for 8-pixel depth tiles (512 x 512 x 40 voxels): one face
+def test_image_border_with_fine_tiles(cuda, oracle, edge, nz):
+    """test_patches_touching_the_image_border on a slab large enough for 8-pixel depth tiles (512 x 512 x 40 voxels) and on one
+    large enough for the 4-pixel fine tables beside them (512 x 512 x 256): one face
     of the volume projects onto an image border, the camera slides in quarter-pixel steps so that the projected boxes of the
     bricks along that face cross 0 / W - 1 / H - 1 and the +- px_margin band around them; alternately a far plane (free-space
     claims need the box INSIDE the image) and a near plane (skip claims), with a column / row of invalid pixels hugging the
@@ -279,7 +283,7 @@ def test_image_border_with_fine_tiles(cuda, oracle, edge):
     import whole_volume as wv
     if not wv.available():
         pytest.skip("oracle/_ref/libtsdf_ref_hip.so not built")
-    dims, vs = (512, 512, 40), 0.002
+    dims, vs = (512, 512, nz), 0.002
     origin = np.array([-0.512, -0.512, 1.0], np.float32)
     near, far = 1.0, 1.0 + dims[2] * vs
     fx, fy = 535.4, 539.2
@@ -309,11 +313,11 @@ def test_image_border_with_fine_tiles(cuda, oracle, edge):
         depths.append(d)
     poses = np.stack(poses)
     dev = [cuda.from_numpy(d).cuda() for d in depths]
-    ref_t, ref_w = wv.replay(cuda, f"border_{edge}", cfg.cam_K, dims, cfg.origin, cfg.voxel_size, cfg.trunc_margin, poses, dev)
+    ref_t, ref_w = wv.replay(cuda, f"border_{edge}{nz}", cfg.cam_K, dims, cfg.origin, cfg.voxel_size, cfg.trunc_margin, poses, dev)
     assert 0 < float((ref_w > 0).sum()) < ref_w.numel(), "the border should cut the volume"
     for variant in (8, 0):
         with capi.Volume(cfg) as vol:
             vol.set_kernel_variant(variant)
             vol.integrate_frames_device([d.data_ptr() for d in dev], poses)
-            wv.assert_volume_equals_reference(cuda, f"image border {edge}, 8-pixel tiles, variant {variant}", vol, ref_t, ref_w, dims)
-    wv.drop(f"border_{edge}")
+            wv.assert_volume_equals_reference(cuda, f"image border {edge}, nz {nz}, variant {variant}", vol, ref_t, ref_w, dims)
+    wv.drop(f"border_{edge}{nz}")

@@ -50,6 +50,16 @@ if [ -f semantic_slam_amd/libtsdf_hip_exp.so ]; then
 import sys, json; d = json.loads(sys.stdin.read().strip()); r = d['roofline']; v = r.get('valu') or {}
 print('S-surf 512^3, list_bucket mode $m: %.5f ms per frame, measured traffic %.1f MB per launch (%.2f x algorithmic), %.2f wavefronts per SIMD, issue-slot share %.3f' % (d['ms_per_step'], (r['traffic'] or 0) / 1e6, r.get('traffic_over_algorithmic') or 0, v.get('mean_waves_per_simd') or 0, v.get('valu_issue_frac') or 0))"
   done > $out/${R}_wedge_modes.txt 2>&1
+  # fine (4-pixel) tiles beside the 8-pixel tables, off / on, same box (the measurement build reads TSDF_FINE_TILES)
+  ( for m in 0 1 0 1; do for w in "--workload ssurf" "--workload traj" "--workload ssurf --noise-mm 2 --holes 0.05"; do
+      echo "fine tiles $m | $w: $(TSDF_HIP_LIB=$PWD/semantic_slam_amd/libtsdf_hip_exp.so TSDF_FINE_TILES=$m python3 bench.py $w --no-extras --no-traffic --no-cpu-baseline 2>> $out/_bench.err | python3 -c "import sys, json; d = json.loads(sys.stdin.read().strip()); print(d['ms_per_step'], 'ms per frame,', d['value'], 'Mvox/s')")"
+    done; done
+    for m in 0 1; do echo "fine tiles $m:"; TSDF_HIP_LIB=$PWD/semantic_slam_amd/libtsdf_hip_exp.so TSDF_FINE_TILES=$m python3 tools/claim_rate.py --workload ssurf --shapes 2,4,8 2>/dev/null | tail -2; done ) > $out/${R}_fine_tiles.txt 2>&1
+  # the caller's frame into the pinned ring: memcpy against streaming stores, same box, the reference's call shape
+  ( echo "memcpy:"; TSDF_HIP_LIB=$PWD/semantic_slam_amd/libtsdf_hip_exp.so TSDF_PLAIN_MEMCPY=1 python3 tools/host_path_time.py 2>/dev/null | head -1
+    echo "streaming stores (what ships):"; TSDF_HIP_LIB=$PWD/semantic_slam_amd/libtsdf_hip_exp.so python3 tools/host_path_time.py 2>/dev/null | head -1
+    echo "memcpy:"; TSDF_HIP_LIB=$PWD/semantic_slam_amd/libtsdf_hip_exp.so TSDF_PLAIN_MEMCPY=1 python3 tools/host_path_time.py 2>/dev/null | head -1
+    echo "streaming stores (what ships):"; TSDF_HIP_LIB=$PWD/semantic_slam_amd/libtsdf_hip_exp.so python3 tools/host_path_time.py 2>/dev/null | head -1 ) >> $out/${R}_host_path_time.txt 2>&1
 fi
 python3 tools/claim_rate.py --workload ssurf --shapes 2,4,8 > $out/${R}_claim_rate.txt 2>&1
 python3 tools/claim_rate.py --workload traj --grid 1024 --shapes 2,4,8 >> $out/${R}_claim_rate.txt 2>&1
