@@ -426,10 +426,14 @@ bool classify_one_frame(const tsdf_volume *v, int64_t launch_voxels)
 
 // Depth tile tables (summary + sparse table, tsdf_multiframe.hip.h) of n images depth[i] x mask[i] into tables[i], queued
 // on `stream`; two small launches per 32 images.
+// fine (may be null; 8-pixel tiles only): the launch's fine tables (p.fine_w x p.fine_h tiles of 4 pixels, nine levels per frame),
+// built by the same two launches whenever the coarse tables fit tile_sparse_table's LDS, else by two more.
 int build_tile_tables(hipStream_t stream, const tsdf_config &c, const tsdfk::IntegrateParams &p, const float *const *depth,
-                      const uint8_t *const *masks, int n, float2 *tables, unsigned long long *zero_me = nullptr)
+                      const uint8_t *const *masks, int n, float2 *tables, unsigned long long *zero_me = nullptr, float2 *fine = nullptr)
 {
     const size_t per = tile_table_elems_host(p.tiles_w, p.tiles_h);
+    if (fine != nullptr && (p.tile_inv != 0.125f || n > tsdfk::kMaxFramesPerLaunch))
+        return fail(TSDF_ERR_INVALID, "build_tile_tables: fine tables go with 8-pixel tiles, one launch at a time");
     for (int k = 0; k < n; k += tsdfk::kMaxFramesPerLaunch) {
         const int m = std::min(tsdfk::kMaxFramesPerLaunch, n - k);
         tsdfk::TileSummaryParams tp;
@@ -440,6 +444,7 @@ int build_tile_tables(hipStream_t stream, const tsdf_config &c, const tsdfk::Int
         tp.tiles = tables + (size_t)k * per;
         tp.H = c.im_height; tp.W = c.im_width; tp.tiles_w = p.tiles_w; tp.tiles_h = p.tiles_h;
         tp.max_depth = c.max_depth;
+        tp.fine = fine; tp.fw = p.fine_w; tp.fh = p.fine_h;      // level (0, 0) of the fine tables in the same pass (8-pixel tiles)
         // whole-row reads: one wavefront per strip of 64 pixels (four 16-pixel tiles or eight 8-pixel ones)
         if (p.tile_inv == 0.0625f) {
             const int strips = ((p.tiles_w + 3) / 4) * p.tiles_h;
@@ -450,12 +455,16 @@ int build_tile_tables(hipStream_t stream, const tsdf_config &c, const tsdfk::Int
         }
         if (p.tiles_w * p.tiles_h <= tsdfk::kTileLdsEntries) {
             // (1024 threads when the frame has thousands of tiles: each of the kernel's ~12 barrier-separated passes visits every tile)
-            hipLaunchKernelGGL(tsdfk::tile_sparse_table, dim3((unsigned)tile_levels_host(p.tiles_w), m), dim3(p.tiles_w * p.tiles_h > 2048 ? 1024 : 256), 0, stream, tp.tiles,
-                               p.tiles_w, p.tiles_h, k == 0 ? zero_me : (unsigned long long *)nullptr);
+            const unsigned threads = p.tiles_w * p.tiles_h > 2048 ? 1024 : 256;
+            const unsigned fine_blocks = fine ? ((unsigned)(p.fine_w * p.fine_h) + threads - 1) / threads : 0u;   // the fine tables' upper levels ride along
+            hipLaunchKernelGGL(tsdfk::tile_sparse_table, dim3((unsigned)tile_levels_host(p.tiles_w) + fine_blocks, m), dim3(threads), 0, stream, tp.tiles,
+                               p.tiles_w, p.tiles_h, k == 0 ? zero_me : (unsigned long long *)nullptr, fine, p.fine_w, p.fine_h);
         } else {
             if (zero_me && k == 0) HIP_TRY(hipMemsetAsync(zero_me, 0, tsdfk::kCounterBytes, stream));
             hipLaunchKernelGGL(tsdfk::tile_sparse_table_scan, dim3((unsigned)tile_levels_host(p.tiles_w), m), dim3(256), 0, stream, tp.tiles,
                                p.tiles_w, p.tiles_h);
+            if (fine)
+                hipLaunchKernelGGL(tsdfk::fine_tile_levels, dim3((unsigned)((p.fine_w * p.fine_h + 255) / 256), m), dim3(256), 0, stream, fine, p.fine_w, p.fine_h);
         }
     }
     HIP_TRY(hipGetLastError());
@@ -718,24 +727,11 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
         float2 *tiles = nullptr;
         int rc = tables_begin(v, &tiles);
         if (rc) return rc;
-        rc = build_tile_tables(v->stream, c, mi.common, depth_dev, masks_dev, n, tiles, v->d_claims);
+        // (fine_tables) the fine tables of the launch's frames sit behind its kMaxFramesPerLaunch coarse ones in the same slot
+        float2 *fine = v->fine_tables ? tiles + (size_t)tsdfk::kMaxFramesPerLaunch * per_frame : nullptr;
+        rc = build_tile_tables(v->stream, c, mi.common, depth_dev, masks_dev, n, tiles, v->d_claims, fine);
         if (rc) return rc;
-        if (v->fine_tables) {
-            // the fine tables of the launch's frames, behind its kMaxFramesPerLaunch coarse ones in the same slot
-            float2 *fine = tiles + (size_t)tsdfk::kMaxFramesPerLaunch * per_frame;
-            tsdfk::FineTileParams fp;
-            for (int f = 0; f < tsdfk::kMaxFramesPerLaunch; ++f) {
-                fp.depth[f] = depth_dev[f < n ? f : 0];
-                fp.mask[f] = masks_dev ? masks_dev[f < n ? f : 0] : nullptr;
-            }
-            fp.fine = fine;
-            fp.H = c.im_height; fp.W = c.im_width; fp.fw = mi.common.fine_w; fp.fh = mi.common.fine_h;
-            fp.max_depth = c.max_depth;
-            hipLaunchKernelGGL(tsdfk::fine_tile_base, dim3((unsigned)((fp.fw + 63) / 64), (unsigned)fp.fh, (unsigned)n), dim3(64), 0, v->stream, fp);
-            hipLaunchKernelGGL(tsdfk::fine_tile_levels, dim3((unsigned)((fp.fw * fp.fh + 255) / 256), (unsigned)n), dim3(256), 0, v->stream, fine, fp.fw, fp.fh);
-            HIP_TRY(hipGetLastError());
-            mi.common.fine = fine;
-        }
+        mi.common.fine = fine;
         for (int f = 0; f < n; ++f) mi.frames[f].tiles = tiles + (size_t)f * per_frame;
         for (int f = n; f < tsdfk::kMaxFramesPerLaunch; ++f) mi.frames[f] = mi.frames[0];
     }
@@ -1849,20 +1845,46 @@ int tsdf_selftest_tile_tables(int32_t device, const float *depth_dev, const uint
         tsdfk::FineTileParams fp;
         for (int f = 0; f < tsdfk::kMaxFramesPerLaunch; ++f) { fp.depth[f] = depth_dev; fp.mask[f] = mask_dev; }
         fp.H = im_height; fp.W = im_width; fp.fw = fw; fp.fh = fh; fp.max_depth = max_depth;
-        fp.fine = d_a;
-        hipLaunchKernelGGL(tsdfk::fine_tile_base, dim3((unsigned)((fw + 63) / 64), (unsigned)fh, 1), dim3(64), 0, 0, fp);
-        hipLaunchKernelGGL(tsdfk::fine_tile_levels, dim3((unsigned)((fw * fh + 255) / 256), 1), dim3(256), 0, 0, d_a, fw, fh);
+        // b: pixel by pixel
         fp.fine = d_b;
         hipLaunchKernelGGL(tsdfk::fine_table_reference, dim3((unsigned)((per + 255) / 256), 1), dim3(256), 0, 0, fp);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipDeviceSynchronize();
         std::vector<float2> a(per), b(per);
-        if (e == hipSuccess) e = hipMemcpy(a.data(), d_a, per * sizeof(float2), hipMemcpyDeviceToHost);
         if (e == hipSuccess) e = hipMemcpy(b.data(), d_b, per * sizeof(float2), hipMemcpyDeviceToHost);
+        // a: the standalone kernels (base tiles, then levels), then what a launch runs -- level (0, 0) out of the 8-pixel strip
+        // kernel's pass, the upper levels by the extra workgroups of the sparse-table kernel
+        for (int how = 0; how < 2 && e == hipSuccess; ++how) {
+            (void)hipMemset(d_a, 0xff, per * sizeof(float2));
+            if (how == 0) {
+                fp.fine = d_a;
+                hipLaunchKernelGGL(tsdfk::fine_tile_base, dim3((unsigned)((fw + 63) / 64), (unsigned)fh, 1), dim3(64), 0, 0, fp);
+                hipLaunchKernelGGL(tsdfk::fine_tile_levels, dim3((unsigned)((fw * fh + 255) / 256), 1), dim3(256), 0, 0, d_a, fw, fh);
+            } else {
+                const int tw = (im_width + 7) / 8, th = (im_height + 7) / 8;
+                if ((int64_t)tw * th > tsdfk::kTileLdsEntries) break;
+                float2 *d_c = nullptr;
+                if (hipMalloc((void **)&d_c, tile_table_elems_host(tw, th) * sizeof(float2)) != hipSuccess) { e = hipErrorOutOfMemory; break; }
+                tsdfk::TileSummaryParams tp;
+                for (int f = 0; f < tsdfk::kMaxFramesPerLaunch; ++f) { tp.depth[f] = depth_dev; tp.mask[f] = mask_dev; }
+                tp.H = im_height; tp.W = im_width; tp.tiles_w = tw; tp.tiles_h = th; tp.max_depth = max_depth;
+                tp.tiles = d_c; tp.fine = d_a; tp.fw = fw; tp.fh = fh;
+                hipLaunchKernelGGL(tsdfk::depth_tile_summary<8>, dim3((unsigned)((((tw + 7) / 8) * th + 3) / 4), 1), dim3(64, 4), 0, 0, tp);
+                const unsigned threads = tw * th > 2048 ? 1024 : 256;
+                hipLaunchKernelGGL(tsdfk::tile_sparse_table, dim3((unsigned)tile_levels_host(tw) + ((unsigned)(fw * fh) + threads - 1) / threads, 1), dim3(threads), 0, 0,
+                                   d_c, tw, th, (unsigned long long *)nullptr, d_a, fw, fh);
+                e = hipGetLastError();
+                if (e == hipSuccess) e = hipDeviceSynchronize();
+                (void)hipFree(d_c);
+            }
+            if (e == hipSuccess) e = hipGetLastError();
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+            if (e == hipSuccess) e = hipMemcpy(a.data(), d_a, per * sizeof(float2), hipMemcpyDeviceToHost);
+            if (e == hipSuccess) for (size_t i = 0; i < per; ++i) bad += std::memcmp(&a[i], &b[i], sizeof(float2)) != 0;
+        }
         (void)hipFree(d_a);
         (void)hipFree(d_b);
         if (e != hipSuccess) return fail(TSDF_ERR_HIP, "tsdf_selftest_tile_tables (fine): %s", hipGetErrorString(e));
-        for (size_t i = 0; i < per; ++i) bad += std::memcmp(&a[i], &b[i], sizeof(float2)) != 0;
     }
     *mismatches = bad;
     return TSDF_OK;

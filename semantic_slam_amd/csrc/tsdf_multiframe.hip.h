@@ -18,6 +18,10 @@
 namespace tsdfk {
 
 constexpr int kMaxFramesPerLaunch = 32;
+// fine depth tiles (see "fine tiles for brick-sized boxes" below)
+constexpr int kFineTile = 4;
+constexpr int kFineLevels = 3;                       // per axis: 1, 2, 4 tiles
+__host__ __device__ inline size_t fine_table_elems(int fw, int fh) { return (size_t)kFineLevels * kFineLevels * fw * fh; }
 
 struct FramePose {
     const float *depth;
@@ -66,6 +70,10 @@ struct TileSummaryParams {
     float2 *tiles;          // n_frames tables
     int H, W, tiles_w, tiles_h;
     float max_depth;
+    // (depth_tile_summary<8> only) level (0, 0) of the launch's fine tables, written in the same pass over the frame: an 8-pixel
+    // tile is four fine (4-pixel) tiles and the strip kernel already holds their pixels.  Null = none.  Layout: fine_table_elems.
+    float2 *fine = nullptr;
+    int fw = 0, fh = 0;
 };
 
 __device__ __forceinline__ int tile_levels(int n) { return 32 - __clz(n); }   // floor(log2 n) + 1, n >= 1
@@ -138,6 +146,9 @@ __global__ __launch_bounds__(256) void depth_tile_summary(TileSummaryParams tp)
     const float inf = __builtin_inff();
     float mn = inf, mx = -inf;
     bool all_valid = true, nan = false;
+    // the lane's share of its two fine tiles (kTile == 8: rows rr and rr + 4 of the strip belong to the fine tiles 2 ty and 2 ty + 1)
+    float fmn[2] = {inf, inf}, fmx[2] = {-inf, -inf};
+    bool fbad[2] = {false, false}, fnan[2] = {false, false};
     const bool vec = (tp.W & 3) == 0 && (reinterpret_cast<uintptr_t>(d) & 15) == 0 &&
                      (m == nullptr || (reinterpret_cast<uintptr_t>(m) & 3) == 0);
 #pragma unroll
@@ -171,6 +182,32 @@ __global__ __launch_bounds__(256) void depth_tile_summary(TileSummaryParams tp)
             const bool valid = (v[j] > 0.0f) & (v[j] <= tp.max_depth);
             all_valid &= valid;
             if (valid) { mn = fminf(mn, v[j]); mx = fmaxf(mx, v[j]); }
+            if constexpr (kTile == 8) {
+                fnan[i] |= v[j] != v[j];
+                fbad[i] |= !valid;
+                if (valid) { fmn[i] = fminf(fmn[i], v[j]); fmx[i] = fmaxf(fmx[i], v[j]); }
+            }
+        }
+    }
+    if constexpr (kTile == 8) {
+        if (tp.fine != nullptr) {      // wave-uniform
+            // a fine tile = the lane's four pixels x the four row groups (lane bits 4, 5); every lane of the wavefront takes part
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float a = fmn[i], b = fmx[i];
+                int bad_i = fbad[i] ? 1 : 0, nan_i = fnan[i] ? 1 : 0;
+                a = fminf(a, __shfl_xor(a, 16)); b = fmaxf(b, __shfl_xor(b, 16));
+                bad_i |= __shfl_xor(bad_i, 16); nan_i |= __shfl_xor(nan_i, 16);
+                a = fminf(a, __shfl_xor(a, 32)); b = fmaxf(b, __shfl_xor(b, 32));
+                bad_i |= __shfl_xor(bad_i, 32); nan_i |= __shfl_xor(nan_i, 32);
+                const int fx = sx * 16 + c4, fy = ty * 2 + i;
+                if (rr == 0 && fx < tp.fw && fy < tp.fh) {
+                    float2 out;
+                    out.x = (bad_i == 0 && nan_i == 0) ? a : -inf;
+                    out.y = nan_i != 0 ? inf : b;
+                    tp.fine[(size_t)f * fine_table_elems(tp.fw, tp.fh) + (size_t)fy * tp.fw + fx] = out;
+                }
+            }
         }
     }
     // the lanes of a tile: kLanesPerTileRow neighbours along the row (lane bits 0 [, 1]) x the four row groups (lane bits 4, 5)
@@ -246,6 +283,40 @@ __global__ __launch_bounds__(256) void tile_sparse_table_scan(float2 *tables, in
     }
 }
 
+// Levels (ky, kx) != (0, 0) of a fine table from its level (0, 0): tile position k reads the up to 4 x 4 base tiles that start
+// there (clipped at the table's edge, as the coarse table's levels are) and writes its eight combinations.
+__device__ __forceinline__ void fine_levels_at(float2 *__restrict__ T, const int fw, const int fh, const int k)
+{
+    const int n = fw * fh;
+    const int ty = k / fw, tx = k - ty * fw;
+    const float inf = __builtin_inff();
+    float2 b[4][4];
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx)
+            b[dy][dx] = (ty + dy < fh && tx + dx < fw) ? T[(size_t)(ty + dy) * fw + tx + dx] : make_float2(inf, -inf);   // neutral
+    // rows first: r[dy][kx] = combination of b[dy][0 .. 2^kx - 1]
+    float2 r[4][kFineLevels];
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy) {
+        r[dy][0] = b[dy][0];
+        r[dy][1] = make_float2(fminf(b[dy][0].x, b[dy][1].x), fmaxf(b[dy][0].y, b[dy][1].y));
+        const float2 hi = make_float2(fminf(b[dy][2].x, b[dy][3].x), fmaxf(b[dy][2].y, b[dy][3].y));
+        r[dy][2] = make_float2(fminf(r[dy][1].x, hi.x), fmaxf(r[dy][1].y, hi.y));
+    }
+#pragma unroll
+    for (int kx = 0; kx < kFineLevels; ++kx) {
+        const float2 c0 = r[0][kx];
+        const float2 c1 = make_float2(fminf(r[0][kx].x, r[1][kx].x), fmaxf(r[0][kx].y, r[1][kx].y));
+        const float2 h2 = make_float2(fminf(r[2][kx].x, r[3][kx].x), fmaxf(r[2][kx].y, r[3][kx].y));
+        const float2 c2 = make_float2(fminf(c1.x, h2.x), fmaxf(c1.y, h2.y));
+        if (kx > 0) T[(size_t)(0 * kFineLevels + kx) * n + k] = c0;
+        T[(size_t)(1 * kFineLevels + kx) * n + k] = c1;
+        T[(size_t)(2 * kFineLevels + kx) * n + k] = c2;
+    }
+}
+
 // The same table by doubling, for frames whose tiles fit LDS (n <= kTileLdsEntries; 640 x 480: 1200): a level is the
 // combination of two entries of the level below -- (0, s + 1) at tx from (0, s) at tx and at min(tx + 2^s, tw - 1), (i + 1, j)
 // from (i, j) at ty and at min(ty + 2^i, th - 1); the clamped partner lies inside the clipped range, and min / max are
@@ -253,11 +324,19 @@ __global__ __launch_bounds__(256) void tile_sparse_table_scan(float2 *tables, in
 // workgroup per (x level j, frame): j + levels_y - 1 steps of two LDS reads per entry with a barrier each, instead of
 // 2^j + 2^i reads per entry.  zero_me (may be null): the launch's counter block (kCounterBytes: the sharded claim counters and
 // work-list lengths, see classify_brick_list), cleared here for the kernels that follow on the stream: saves a memset dispatch.
-__global__ __launch_bounds__(1024) void tile_sparse_table(float2 *tables, int tw, int th, unsigned long long *zero_me)
+// fine (may be null): the launch's fine tables, level (0, 0) written by depth_tile_summary<8>; the workgroups past the lj level
+// workgroups of a frame compute their upper levels (fine_levels_at), blockDim.x tile positions each -- no launch of their own.
+__global__ __launch_bounds__(1024) void tile_sparse_table(float2 *tables, int tw, int th, unsigned long long *zero_me,
+                                                          float2 *fine = nullptr, int fw = 0, int fh = 0)
 {
     if (zero_me != nullptr && blockIdx.x == 0 && blockIdx.y == 0)
         for (int k = threadIdx.x; k < kCounterBytes / 16; k += blockDim.x) reinterpret_cast<uint4 *>(zero_me)[k] = make_uint4(0u, 0u, 0u, 0u);
     const int lj = tile_levels(tw), li = tile_levels(th), n = tw * th;
+    if ((int)blockIdx.x >= lj) {       // workgroup-uniform
+        const int k = ((int)blockIdx.x - lj) * (int)blockDim.x + (int)threadIdx.x;
+        if (fine != nullptr && k < fw * fh) fine_levels_at(fine + (size_t)blockIdx.y * fine_table_elems(fw, fh), fw, fh, k);
+        return;
+    }
     const int j = blockIdx.x;
     float2 *T = tables + (size_t)blockIdx.y * tile_table_elems(tw, th);
     __shared__ float2 buf[2][kTileLdsEntries];
@@ -303,10 +382,6 @@ __global__ __launch_bounds__(1024) void tile_sparse_table(float2 *tables, int tw
 // x = smallest depth if every pixel passes the reference's range test else -inf, y = largest passing depth or -inf, a NaN
 // poisons its tile to (-inf, +inf); levels combine by min / max -- exact and order-free, so any evaluation order gives the
 // table fine_table_reference computes pixel by pixel (tsdf_selftest_tile_tables compares them bit for bit).
-constexpr int kFineTile = 4;
-constexpr int kFineLevels = 3;                       // per axis: 1, 2, 4 tiles
-__host__ __device__ inline size_t fine_table_elems(int fw, int fh) { return (size_t)kFineLevels * kFineLevels * fw * fh; }
-
 struct FineTileParams {
     const float *depth[kMaxFramesPerLaunch];
     const uint8_t *mask[kMaxFramesPerLaunch];
@@ -367,41 +442,13 @@ __global__ __launch_bounds__(64) void fine_tile_base(FineTileParams tp)
     tp.fine[(size_t)f * fine_table_elems(tp.fw, tp.fh) + (size_t)ty * tp.fw + tx] = out;
 }
 
-// Levels (ky, kx) != (0, 0) from level (0, 0): one thread per tile position reads the up to 4 x 4 base tiles that start there
-// (clipped at the table's edge, as the coarse table's levels are) and writes its eight combinations.
-// grid = (ceil(fw * fh / 256), frames), block = 256.
+// The fine levels as a launch of their own (self-test; frames whose coarse tables do not fit tile_sparse_table's LDS): one thread per
+// tile position.  grid = (ceil(fw * fh / 256), frames), block = 256.
 __global__ __launch_bounds__(256) void fine_tile_levels(float2 *fine, int fw, int fh)
 {
-    const int k = blockIdx.x * 256 + threadIdx.x, n = fw * fh;
-    if (k >= n) return;
-    float2 *T = fine + (size_t)blockIdx.y * fine_table_elems(fw, fh);
-    const int ty = k / fw, tx = k - ty * fw;
-    const float inf = __builtin_inff();
-    float2 b[4][4];
-#pragma unroll
-    for (int dy = 0; dy < 4; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < 4; ++dx)
-            b[dy][dx] = (ty + dy < fh && tx + dx < fw) ? T[(size_t)(ty + dy) * fw + tx + dx] : make_float2(inf, -inf);   // neutral
-    // rows first: r[dy][kx] = combination of b[dy][0 .. 2^kx - 1]
-    float2 r[4][kFineLevels];
-#pragma unroll
-    for (int dy = 0; dy < 4; ++dy) {
-        r[dy][0] = b[dy][0];
-        r[dy][1] = make_float2(fminf(b[dy][0].x, b[dy][1].x), fmaxf(b[dy][0].y, b[dy][1].y));
-        const float2 hi = make_float2(fminf(b[dy][2].x, b[dy][3].x), fmaxf(b[dy][2].y, b[dy][3].y));
-        r[dy][2] = make_float2(fminf(r[dy][1].x, hi.x), fmaxf(r[dy][1].y, hi.y));
-    }
-#pragma unroll
-    for (int kx = 0; kx < kFineLevels; ++kx) {
-        const float2 c0 = r[0][kx];
-        const float2 c1 = make_float2(fminf(r[0][kx].x, r[1][kx].x), fmaxf(r[0][kx].y, r[1][kx].y));
-        const float2 h2 = make_float2(fminf(r[2][kx].x, r[3][kx].x), fmaxf(r[2][kx].y, r[3][kx].y));
-        const float2 c2 = make_float2(fminf(c1.x, h2.x), fmaxf(c1.y, h2.y));
-        if (kx > 0) T[(size_t)(0 * kFineLevels + kx) * n + k] = c0;
-        T[(size_t)(1 * kFineLevels + kx) * n + k] = c1;
-        T[(size_t)(2 * kFineLevels + kx) * n + k] = c2;
-    }
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= fw * fh) return;
+    fine_levels_at(fine + (size_t)blockIdx.y * fine_table_elems(fw, fh), fw, fh, k);
 }
 
 // The same table pixel by pixel (self-test only): one thread per (level, tile position).
