@@ -77,6 +77,8 @@ constexpr bool kExperiments = false;
 #define TSDF_BRICK_NT 0
 #endif
 constexpr bool kBrickNT = TSDF_BRICK_NT != 0;
+// one launch's counter block: the sharded counters / list heads, then the frames' table for classify_patch
+constexpr size_t kClaimBlockBytes = (tsdfk::kCounterBytes + sizeof(tsdfk::ClassPoseTable) + 255) / 256 * 256;
 // How classify_brick_list deals super-bricks to the 64 sub-lists (tsdf_multiframe.hip.h, list_bucket): 0 = hashed, 1 = the XCD
 // by image-row wedges.
 #ifndef TSDF_WEDGE_MODE
@@ -154,8 +156,23 @@ struct tsdf_volume {
     // optional diagnostic counters (tsdf_shortcut_stats)
     unsigned int *d_shortcut_stats;
     // adaptive use of the classification: claims of the last classifying launch, read back without blocking
-    unsigned long long *d_claims, *h_claims;
+    unsigned long long *d_claims, *h_claims;   // d_claims: TWO counter blocks (+ frame table each), one per list parity
     hipEvent_t claims_done;
+    // A sequence call's launches are pipelined: the pre-pass of launch k + 1 (tile tables, classify_brick_list: small grids, 11 % of
+    // a 512^3 S-surf launch, reading only the frames and the poses) runs on pre_stream beside launch k's Integrate kernel.  Two work
+    // lists, two counter blocks, two table slots (list_parity); pre_done[p]: pre-pass of parity p queued on pre_stream; list_free[p]:
+    // the Integrate kernel that read parity p's list has been queued on the handle's stream; seq_ready: a sequence's inputs.
+    hipStream_t pre_stream = nullptr, rb_stream = nullptr;   // rb_stream: the counters' read-back of a pipelined launch
+    int rb_parity = -1;                                      // parity of the block the read-back in flight on rb_stream reads, or -1
+    hipEvent_t pre_done[2] = {nullptr, nullptr}, list_free[2] = {nullptr, nullptr}, seq_ready = nullptr;
+    int list_parity = 0;
+    bool list_used[2] = {false, false};
+    // Pipelining pays where a launch is short enough for its small pre-pass kernels to matter and the chip is not full: measured,
+    // same box, sequence path, pre-pass on the handle's stream / beside the previous launch: S-surf 200^3 0.00578 -> 0.00546 ms per
+    // frame, 320^3 0.01043 -> 0.01037, 512^3 0.02396 -> 0.02403 (the Integrate kernel runs 76 us longer beside a pre-pass that takes
+    // 84 us alone: its latency-bound wavefronts hold slots the Integrate kernel's would use), fr3 trajectory 1024^3 0.1460 -> 0.1458.
+    // So: slabs below 64 M voxels; larger ones keep one list (the second would be 134 MB at 1024^3) and one stream.
+    bool pipeline_ok = false;
     bool claims_pending, claims_known;
     double claims_total;        // workgroup-frames of the launch the pending read-back belongs to
     double claim_fraction;      // claimed / total of the last launch that was read back
@@ -271,10 +288,10 @@ void store_next_pass(tsdf_volume *v) { v->flush_parity ^= 1; }
 
 // The depth tile tables of the launch being queued (kMaxFramesPerLaunch tables): a table slot of the store, first written on the
 // handle's stream; tables_end() after the launch that reads them has been queued.
-int tables_begin(tsdf_volume *v, float2 **tiles)
+int tables_begin(tsdf_volume *v, float2 **tiles, hipStream_t first_user = nullptr)
 {
     void *dev = nullptr;
-    hipError_t e = tsdf_store::slot_acquire(v->store, &v->store->tables, v, v->stream, true, &v->table_slot, &dev);
+    hipError_t e = tsdf_store::slot_acquire(v->store, &v->store->tables, v, first_user ? first_user : v->stream, true, &v->table_slot, &dev);
     if (e != hipSuccess) return fail(TSDF_ERR_HIP, "frame store (tile tables): %s", hipGetErrorString(e));
     *tiles = static_cast<float2 *>(dev);
     return TSDF_OK;
@@ -428,8 +445,12 @@ bool classify_one_frame(const tsdf_volume *v, int64_t launch_voxels)
 // on `stream`; two small launches per 32 images.
 // fine (may be null; 8-pixel tiles only): the launch's fine tables (p.fine_w x p.fine_h tiles of 4 pixels, nine levels per frame),
 // built by the same two launches whenever the coarse tables fit tile_sparse_table's LDS, else by two more.
+// beside_a_launch: the kernels are queued on a side stream while another launch fills the chip -- the sparse-table kernel then takes
+// 256-thread workgroups (a 1024-thread one needs sixteen free wavefront slots on ONE compute unit at once and waited for the other
+// launch to drain: 634 us instead of 20).
 int build_tile_tables(hipStream_t stream, const tsdf_config &c, const tsdfk::IntegrateParams &p, const float *const *depth,
-                      const uint8_t *const *masks, int n, float2 *tables, unsigned long long *zero_me = nullptr, float2 *fine = nullptr)
+                      const uint8_t *const *masks, int n, float2 *tables, unsigned long long *zero_me = nullptr, float2 *fine = nullptr,
+                      bool beside_a_launch = false)
 {
     const size_t per = tile_table_elems_host(p.tiles_w, p.tiles_h);
     if (fine != nullptr && (p.tile_inv != 0.125f || n > tsdfk::kMaxFramesPerLaunch))
@@ -455,7 +476,7 @@ int build_tile_tables(hipStream_t stream, const tsdf_config &c, const tsdfk::Int
         }
         if (p.tiles_w * p.tiles_h <= tsdfk::kTileLdsEntries) {
             // (1024 threads when the frame has thousands of tiles: each of the kernel's ~12 barrier-separated passes visits every tile)
-            const unsigned threads = p.tiles_w * p.tiles_h > 2048 ? 1024 : 256;
+            const unsigned threads = (p.tiles_w * p.tiles_h > 2048 && !beside_a_launch) ? 1024 : 256;
             const unsigned fine_blocks = fine ? ((unsigned)(p.fine_w * p.fine_h) + threads - 1) / threads : 0u;   // the fine tables' upper levels ride along
             hipLaunchKernelGGL(tsdfk::tile_sparse_table, dim3((unsigned)tile_levels_host(p.tiles_w) + fine_blocks, m), dim3(threads), 0, stream, tp.tiles,
                                p.tiles_w, p.tiles_h, k == 0 ? zero_me : (unsigned long long *)nullptr, fine, p.fine_w, p.fine_h);
@@ -538,7 +559,7 @@ int rebuild_summary(tsdf_volume *v)
 }
 
 int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *const *masks_dev, const float *c2b, int n,
-                 const uint16_t *const *label_ims = nullptr, const float *const *score_ims = nullptr);
+                 const uint16_t *const *label_ims = nullptr, const float *const *score_ims = nullptr, hipEvent_t inputs_ready = nullptr);
 
 // Claimed share of the launch whose counter block has arrived in h_claims: (free << 32 | skipped) per bucket, added up.
 double claims_read_back(const tsdf_volume *v)
@@ -617,8 +638,11 @@ void compose_cam2base(const tsdf_volume *v, const float *cam2world, float *c2b)
 
 // n frames (n <= kMaxFramesPerLaunch) in one pass over the slab.  c2b: n x 16 relative poses.
 // label_ims / score_ims (both or neither): the frames' label evidence is fused in the same pass (LABELS kernels).
+// inputs_ready (may be null): an event after which the frames (and masks) may be read from ANY stream -- a sequence call records it
+// once on the handle's stream at its start; with it the pre-pass of a classified launch runs on the handle's side stream, i.e.
+// beside the previous launch's Integrate kernel (see tsdf_volume::pre_stream).  Null: everything on the handle's stream.
 int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *const *masks_dev,
-                 const float *c2b, int n, const uint16_t *const *label_ims, const float *const *score_ims)
+                 const float *c2b, int n, const uint16_t *const *label_ims, const float *const *score_ims, hipEvent_t inputs_ready)
 {
     const tsdf_config &c = v->cfg;
     const int nz = c.z_end - c.z_begin;
@@ -706,30 +730,65 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
         // all three or none: a launch that finds d_claims set relies on the host mirror and the event being there too
         unsigned long long *dc = nullptr;
         unsigned char *hc = nullptr;
-        hipEvent_t ev = nullptr;
-        hipError_t e = hipMalloc((void **)&dc, tsdfk::kCounterBytes + sizeof(tsdfk::ClassPoseTable));
+        hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        hipStream_t ps = nullptr;
+        hipError_t e = hipMalloc((void **)&dc, 2 * kClaimBlockBytes);
         if (e == hipSuccess) e = hipHostMalloc((void **)&hc, tsdfk::kCounterBytes, hipHostMallocDefault);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        for (int i = 0; i < 6 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+        if (e == hipSuccess) {
+            // (default priority unless the measurement build asks: with the highest one the pre-pass finished 180 us into the launch
+            // beside it, which then ran 65 us longer -- nothing gained)
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // (numerically lower = higher priority)
+            int prio = 0;
+#ifdef TSDF_EXPERIMENTS
+            if (std::getenv("TSDF_PRE_PRIORITY")) prio = hi;
+#endif
+            e = hipStreamCreateWithPriority(&ps, hipStreamNonBlocking, prio);
+        }
+        hipStream_t rbs = nullptr;
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&rbs, hipStreamNonBlocking);
         if (e != hipSuccess) {
-            if (ev) (void)hipEventDestroy(ev);
+            if (rbs) (void)hipStreamDestroy(rbs);
+            if (ps) (void)hipStreamDestroy(ps);
+            for (int i = 0; i < 6; ++i) if (ev[i]) (void)hipEventDestroy(ev[i]);
             if (hc) (void)hipHostFree(hc);
             if (dc) (void)hipFree(dc);
             return fail(TSDF_ERR_HIP, "claim counters: %s", hipGetErrorString(e));
         }
         v->d_claims = reinterpret_cast<decltype(v->d_claims)>(dc);
         v->h_claims = reinterpret_cast<decltype(v->h_claims)>(hc);
-        v->claims_done = ev;
+        v->claims_done = ev[0];
+        v->pre_done[0] = ev[1]; v->pre_done[1] = ev[2]; v->list_free[0] = ev[3]; v->list_free[1] = ev[4]; v->seq_ready = ev[5];
+        v->pre_stream = ps;
+        v->rb_stream = rbs;
     }
-    if (count_claims) mi.common.claim_counter = v->d_claims + 1;   // bucket 0's claims word (the pre-pass adds the bucket's offset)
+    // this launch's parity: its counter block, its half of the work list, its table slot
+    // (slabs too large to be pipelined -- see pipeline_ok -- keep one list and one parity)
+    const int P = v->pipeline_ok ? v->list_parity : 0;
+    unsigned long long *const claims_p = classify ? v->d_claims + (size_t)P * (kClaimBlockBytes / sizeof(unsigned long long)) : nullptr;
+    bool pipelined = classify && inputs_ready != nullptr && v->pipeline_ok;
+#ifdef TSDF_EXPERIMENTS
+    if (!shipped_variant(v->variant) || std::getenv("TSDF_NO_PIPELINE")) pipelined = false;   // the measurement build's own kernels run on the handle's stream
+#endif
+    const hipStream_t ps = pipelined ? v->pre_stream : v->stream;
+    if (pipelined) {
+        HIP_TRY(hipStreamWaitEvent(ps, inputs_ready, 0));
+        if (v->list_used[P]) HIP_TRY(hipStreamWaitEvent(ps, v->list_free[P], 0));   // the Integrate kernel two launches back has read this parity's buffers
+        if (v->rb_parity == P) HIP_TRY(hipStreamWaitEvent(ps, v->claims_done, 0)); // ... and its counters have left for the host
+    } else if (classify && v->rb_parity == P) {
+        HIP_TRY(hipStreamWaitEvent(v->stream, v->claims_done, 0));
+    }
+    if (count_claims) mi.common.claim_counter = claims_p + 1;   // bucket 0's claims word (the pre-pass adds the bucket's offset)
     if (classify) {
         // depth tile tables of the n frames (two small launches), then the kernels that consult them
         const size_t per_frame = tile_table_elems_host(mi.common.tiles_w, mi.common.tiles_h);
         float2 *tiles = nullptr;
-        int rc = tables_begin(v, &tiles);
+        int rc = tables_begin(v, &tiles, ps);
         if (rc) return rc;
         // (fine_tables) the fine tables of the launch's frames sit behind its kMaxFramesPerLaunch coarse ones in the same slot
         float2 *fine = v->fine_tables ? tiles + (size_t)tsdfk::kMaxFramesPerLaunch * per_frame : nullptr;
-        rc = build_tile_tables(v->stream, c, mi.common, depth_dev, masks_dev, n, tiles, v->d_claims, fine);
+        rc = build_tile_tables(ps, c, mi.common, depth_dev, masks_dev, n, tiles, claims_p, fine, pipelined);
         if (rc) return rc;
         mi.common.fine = fine;
         for (int f = 0; f < n; ++f) mi.frames[f].tiles = tiles + (size_t)f * per_frame;
@@ -737,7 +796,7 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
     }
     const int nz_groups = (nz + mi.common.brick_s - 1) / mi.common.brick_s;   // a brick spans brick_s slices
     double claims_total = 0.0;
-    bool launched = false;
+    bool launched = false, listed = false;
 #ifdef TSDF_EXPERIMENTS
     {
         int rc = launch_multi_experiment(v, mi, depth_dev, masks_dev, c2b, n, label_ims != nullptr, any_mask, classify, &launched, &claims_total);
@@ -777,19 +836,28 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
         const int64_t total = cap * tsdfk::kListBuckets;
         if (total > 0x7fffffffll - 1024) return fail(TSDF_ERR_INVALID, "fused launch: %lld bricks exceed the work list's 32-bit index", (long long)total);
         if (v->work_entries < (size_t)total) {
-            if (v->d_work) HIP_TRY(hipFree(v->d_work));
+            if (v->d_work) {      // (a list in flight on either stream is done before its memory goes)
+                HIP_TRY(hipStreamSynchronize(v->pre_stream));
+                HIP_TRY(hipStreamSynchronize(v->stream));
+                HIP_TRY(hipFree(v->d_work));
+            }
             v->d_work = nullptr;
             v->work_entries = 0;
-            HIP_TRY(hipMalloc((void **)&v->d_work, (size_t)total * sizeof(uint4)));
+            HIP_TRY(hipMalloc((void **)&v->d_work, (v->pipeline_ok ? 2 : 1) * (size_t)total * sizeof(uint4)));     // one list per parity
             v->work_entries = (size_t)total;
         }
-        bl.list = v->d_work;
-        bl.counters = reinterpret_cast<unsigned char *>(v->d_claims);
+        uint4 *const work_p = v->d_work + (size_t)P * v->work_entries;
+        bl.list = work_p;
+        bl.counters = reinterpret_cast<unsigned char *>(claims_p);
         bl.bucket_cap = (unsigned int)cap;
         bl.poses = reinterpret_cast<tsdfk::ClassPoseTable *>(bl.counters + tsdfk::kCounterBytes);
-        hipLaunchKernelGGL(tsdfk::classify_brick_list, dim3((unsigned)((n_super + 3) / 4)), block, 0, v->stream, mi, bl);
+        hipLaunchKernelGGL(tsdfk::classify_brick_list, dim3((unsigned)((n_super + 3) / 4)), block, 0, ps, mi, bl);
+        if (pipelined) {       // the Integrate kernel waits for its pre-pass; everything before it on the handle's stream does not
+            HIP_TRY(hipEventRecord(v->pre_done[P], ps));
+            HIP_TRY(hipStreamWaitEvent(v->stream, v->pre_done[P], 0));
+        }
         const dim3 grid_list((unsigned)(((cap + 3) / 4 + 1) * tsdfk::kListBuckets));   // front groups + back groups of every sub-list
-        const uint4 *wl = v->d_work;
+        const uint4 *wl = work_p;
         const unsigned char *wc = bl.counters;
         const tsdfk::ClassPoseTable *wp = bl.poses;
         if (label_ims)
@@ -800,6 +868,7 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
             hipLaunchKernelGGL((tsdfk::integrate_brick_list<kBrickNT, false, false>), grid_list, block, 0, v->stream, mi, wl, wc, bl.bucket_cap, wp);
         claims_total = (double)per_group * nz_groups * n;   // wavefront-frames = bricks x frames
         launched = true;
+        listed = true;
     }
     if (!launched) {
         // The per-voxel fused kernel.  Workgroup order: slices fastest -- consecutively dispatched workgroups share their
@@ -826,14 +895,30 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
         else
             hipLaunchKernelGGL((tsdfk::integrate_multi_inline<1, true, false, false, false>), grid_rows, block, 0, v->stream, mi);
     }
+    if (listed) {
+        // after this parity's Integrate kernel: its buffers may be rebuilt (a pre-pass on the side stream waits for it)
+        HIP_TRY(hipEventRecord(v->list_free[P], v->stream));
+        v->list_used[P] = true;
+        v->list_parity = v->pipeline_ok ? P ^ 1 : 0;
+    }
     if (count_claims) {
+        // the counters' way to the host: on a stream of its own when the launch is pipelined (behind list_free, i.e. after the
+        // Integrate kernel), so that the copy sits neither between two Integrate kernels on the handle's stream nor in front of the
+        // next pre-pass on the side stream; the pre-pass that clears this block again waits for it (rb_done)
         v->claims_total = claims_total;
-        HIP_TRY(hipMemcpyAsync(v->h_claims, v->d_claims, tsdfk::kCounterBytes, hipMemcpyDeviceToHost, v->stream));
-        HIP_TRY(hipEventRecord(v->claims_done, v->stream));
+        const hipStream_t rs = (pipelined && listed) ? v->rb_stream : v->stream;
+        if (rs != v->stream) HIP_TRY(hipStreamWaitEvent(rs, v->list_free[P], 0));
+        HIP_TRY(hipMemcpyAsync(v->h_claims, claims_p, tsdfk::kCounterBytes, hipMemcpyDeviceToHost, rs));
+        HIP_TRY(hipEventRecord(v->claims_done, rs));
         v->claims_pending = true;
+        v->rb_parity = (rs != v->stream) ? P : -1;
     }
     HIP_TRY(hipGetLastError());
-    return tables_end(v);
+    const int rc_end = tables_end(v);
+    // (pipelined) the next launch's table slot is released after the OTHER of the handle's two events: a slot taken two launches
+    // later then waits for this launch's Integrate kernel, not for the one in between
+    if (pipelined) store_next_pass(v);
+    return rc_end;
 }
 
 // Frames applied per pass over the slab.  Per frame the time is a + b / n: the weights are read and written,
@@ -856,11 +941,18 @@ int integrate_frames(tsdf_volume *v, const float *const *depth_dev, const uint8_
 {
     const bool fuse = can_fuse(v);
     int rc = TSDF_OK;
+    // every frame of the sequence is readable once what precedes this call on the handle's stream has run: one event for all its
+    // launches, so that their pre-passes may run beside the launches ahead of them (launch_multi, inputs_ready)
+    bool seq_event = false;
     for (int k = 0; k < n_frames && rc == TSDF_OK;) {
         const int n = fuse ? std::min(frames_per_launch(v), n_frames - k) : 1;
         float c2b[16 * tsdfk::kMaxFramesPerLaunch];
         for (int i = 0; i < n; ++i) compose_cam2base(v, cam2world + 16 * (k + i), c2b + 16 * i);
-        if (fuse) rc = launch_multi(v, depth_dev + k, masks_dev ? masks_dev + k : nullptr, c2b, n);
+        if (fuse && !seq_event && v->seq_ready && n_frames > n) {
+            HIP_TRY(hipEventRecord(v->seq_ready, v->stream));
+            seq_event = true;
+        }
+        if (fuse) rc = launch_multi(v, depth_dev + k, masks_dev ? masks_dev + k : nullptr, c2b, n, nullptr, nullptr, seq_event ? v->seq_ready : nullptr);
         else rc = launch_integrate(v, depth_dev[k], masks_dev ? masks_dev[k] : nullptr, c2b);
         k += n;
     }
@@ -1236,6 +1328,10 @@ int tsdf_create(const tsdf_config *cfg, tsdf_volume **out)
     // allocated until a frame arrives)
     v->tile = tile_edge_for(*cfg);
     v->fine_tables = fine_tables_for(*cfg, v->tile);
+    v->pipeline_ok = (int64_t)cfg->dim_x * cfg->dim_y * (int64_t)(cfg->z_end - cfg->z_begin) < kFineLevelMinVoxels;
+#ifdef TSDF_EXPERIMENTS
+    if (const char *e = std::getenv("TSDF_PIPELINE")) v->pipeline_ok = std::atoi(e) != 0;     // A/B knob of the measurement build
+#endif
     {
         const int tw = (cfg->im_width + v->tile - 1) / v->tile, th = (cfg->im_height + v->tile - 1) / v->tile;
         const int fw = (cfg->im_width + tsdfk::kFineTile - 1) / tsdfk::kFineTile, fh = (cfg->im_height + tsdfk::kFineTile - 1) / tsdfk::kFineTile;
@@ -1262,6 +1358,8 @@ int tsdf_destroy(tsdf_volume *v)
     if (v->own_stream) (void)hipStreamSynchronize(v->own_stream);
     if (v->stream && v->stream != v->own_stream) (void)hipStreamSynchronize(v->stream);
     if (v->copy_stream) (void)hipStreamSynchronize(v->copy_stream);
+    if (v->pre_stream) (void)hipStreamSynchronize(v->pre_stream);
+    if (v->rb_stream) (void)hipStreamSynchronize(v->rb_stream);
     v->pend_count = 0;   // frames collected but never observed: nothing can tell whether they were applied
     if (v->store) {      // (the streams are idle: whatever this handle held, or others were waiting on its events for, is free)
         tsdf_store::slots_drop_owner(v->store, v);
@@ -1293,6 +1391,13 @@ int tsdf_destroy(tsdf_volume *v)
     if (v->d_claims) (void)hipFree(v->d_claims);
     if (v->h_claims) (void)hipHostFree(v->h_claims);
     if (v->claims_done) (void)hipEventDestroy(v->claims_done);
+    for (int i = 0; i < 2; ++i) {
+        if (v->pre_done[i]) (void)hipEventDestroy(v->pre_done[i]);
+        if (v->list_free[i]) (void)hipEventDestroy(v->list_free[i]);
+    }
+    if (v->seq_ready) (void)hipEventDestroy(v->seq_ready);
+    if (v->pre_stream) (void)hipStreamDestroy(v->pre_stream);
+    if (v->rb_stream) (void)hipStreamDestroy(v->rb_stream);
     if (v->d_shortcut_stats) (void)hipFree(v->d_shortcut_stats);
     if (v->d_tsdf) (void)hipFree(v->d_tsdf);
     if (v->d_weight) (void)hipFree(v->d_weight);
@@ -1470,11 +1575,16 @@ int tsdf_integrate_frames_labels_device(tsdf_volume *v, const float *const *dept
             return fail(TSDF_ERR_INVALID, "tsdf_integrate_frames_labels_device: frame %d has a NULL image", k);
     int rc = bind_device(v);
     if (rc) return rc;
+    bool seq_event = false;      // as integrate_frames: one "inputs readable" event for all launches of the sequence
     for (int k = 0; k < n_frames && rc == TSDF_OK;) {
         const int n = std::min(frames_per_launch(v), n_frames - k);
         float c2b[16 * tsdfk::kMaxFramesPerLaunch];
         for (int i = 0; i < n; ++i) compose_cam2base(v, cam2world + 16 * (k + i), c2b + 16 * i);
-        rc = launch_multi(v, depth_dev + k, nullptr, c2b, n, label_im_dev + k, score_im_dev + k);
+        if (!seq_event && v->seq_ready && n_frames > n) {
+            HIP_TRY(hipEventRecord(v->seq_ready, v->stream));
+            seq_event = true;
+        }
+        rc = launch_multi(v, depth_dev + k, nullptr, c2b, n, label_im_dev + k, score_im_dev + k, seq_event ? v->seq_ready : nullptr);
         k += n;
     }
     return rc;
@@ -1603,6 +1713,7 @@ int tsdf_classification_info(tsdf_volume *v, double info_out[2])
     int rc = bind_device(v);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(v->stream));
+    if (v->rb_stream) HIP_TRY(hipStreamSynchronize(v->rb_stream));     // (a pipelined launch's counters travel on their own stream)
     if (v->claims_pending && hipEventQuery(v->claims_done) == hipSuccess) {
         v->claim_fraction = claims_read_back(v);
         v->claims_pending = false;
