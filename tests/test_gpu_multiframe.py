@@ -224,3 +224,64 @@ def test_wide_slices_fall_back_to_memory_order(cuda, oracle):
     assert free > 0 and skipped > 0 and per_voxel > 0 and per_voxel + free + skipped == 3 * (4096 // 8) * (2048 // 4)
     assert np.array_equal(w, ref_w) and np.array_equal(t.view(np.uint32), ref_t.view(np.uint32))
     assert ref_w.max() == 3 and ref_w.min() < 3
+
+
+@pytest.mark.parametrize("variant", [8, 0])
+def test_pipelined_sequence_calls_keep_call_order(cuda, oracle, variant):
+    """A sequence call on a slab below 64 M voxels runs the pre-pass of launch k + 1 (depth tile tables, the brick work list) on a
+    side stream beside launch k's Integrate kernel, with two work lists, two counter blocks and two table slots in turn
+    (csrc/tsdf_capi.hip, launch_multi).  Many launches per call (7, then 3, then 5: the parity of the buffers changes between
+    calls), a different depth frame for every pose, frames that update nothing in between, and calls of other kinds wedged between
+    the sequence calls -- one frame through its own launch, a download, a host-pointer frame that is collected and flushed by the
+    next call: the result must be the oracle's for the same frames in call order, bit for bit."""
+    dims, vs = (200, 96, 64), 0.01
+    origin = synth.surf_volume(200, vs, 0.7)
+    cfg = capi.make_config(dims, vs, origin)
+    scene = synth.SurfScene(dims, vs, origin)
+    ref_t, ref_w = oracle.init_grid(dims)
+
+    def frame(k):
+        c2w = scene.pose(k % 37, n=37)
+        depth = scene.depth(c2w, quantize=True) if k % 11 else np.zeros((480, 640), np.float32)     # every eleventh: nothing to see
+        return c2w, depth
+
+    def oracle_apply(fr):
+        for c2w, depth in fr:
+            oracle.integrate(cfg.cam_K, c2w, depth, dims, origin, vs, cfg.trunc_margin, ref_t, ref_w)
+
+    keep = []
+
+    def sequence(vol, fr):
+        dev = [cuda.from_numpy(d).cuda() for _, d in fr]
+        keep.append(dev)
+        vol.integrate_frames_device([d.data_ptr() for d in dev], np.stack([p for p, _ in fr]))
+
+    with capi.Volume(cfg) as vol:
+        vol.set_kernel_variant(variant)
+        a = [frame(k) for k in range(0, 7 * 32 - 5)]
+        sequence(vol, a)
+        oracle_apply(a)
+        one = frame(500)
+        d_one = cuda.from_numpy(one[1]).cuda()
+        vol.set_deferral(0)
+        vol.integrate_device(d_one.data_ptr(), one[0])                  # its own launch on the handle's stream
+        oracle_apply([one])
+        b = [frame(k) for k in range(300, 300 + 3 * 32)]
+        sequence(vol, b)
+        oracle_apply(b)
+        t, w = vol.download()
+        assert np.array_equal(w, ref_w) and np.array_equal(t.view(np.uint32), ref_t.view(np.uint32)), "after the second sequence"
+        vol.set_deferral(32)
+        host = frame(700)
+        vol.integrate(host[1], host[0])                                 # collected; the next call applies it first
+        oracle_apply([host])
+        c = [frame(k) for k in range(800, 800 + 5 * 32 + 1)]
+        sequence(vol, c)
+        oracle_apply(c)
+        frac, idle = vol.classification_info()
+        t, w = vol.download()
+    assert ref_w.max() > 100 and (ref_t != 1.0).sum() > 10000
+    assert np.array_equal(w, ref_w), f"weights differ at {np.flatnonzero(w != ref_w)[:5]}"
+    assert np.array_equal(t.view(np.uint32), ref_t.view(np.uint32))
+    if variant == 8:
+        assert idle == 0 and frac > 0.3, (frac, idle)
