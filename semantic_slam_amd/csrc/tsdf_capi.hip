@@ -731,26 +731,10 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
         unsigned long long *dc = nullptr;
         unsigned char *hc = nullptr;
         hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-        hipStream_t ps = nullptr;
         hipError_t e = hipMalloc((void **)&dc, 2 * kClaimBlockBytes);
         if (e == hipSuccess) e = hipHostMalloc((void **)&hc, tsdfk::kCounterBytes, hipHostMallocDefault);
         for (int i = 0; i < 6 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
-        if (e == hipSuccess) {
-            // (default priority unless the measurement build asks: with the highest one the pre-pass finished 180 us into the launch
-            // beside it, which then ran 65 us longer -- nothing gained)
-            int lo = 0, hi = 0;
-            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // (numerically lower = higher priority)
-            int prio = 0;
-#ifdef TSDF_EXPERIMENTS
-            if (std::getenv("TSDF_PRE_PRIORITY")) prio = hi;
-#endif
-            e = hipStreamCreateWithPriority(&ps, hipStreamNonBlocking, prio);
-        }
-        hipStream_t rbs = nullptr;
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&rbs, hipStreamNonBlocking);
         if (e != hipSuccess) {
-            if (rbs) (void)hipStreamDestroy(rbs);
-            if (ps) (void)hipStreamDestroy(ps);
             for (int i = 0; i < 6; ++i) if (ev[i]) (void)hipEventDestroy(ev[i]);
             if (hc) (void)hipHostFree(hc);
             if (dc) (void)hipFree(dc);
@@ -760,8 +744,6 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
         v->h_claims = reinterpret_cast<decltype(v->h_claims)>(hc);
         v->claims_done = ev[0];
         v->pre_done[0] = ev[1]; v->pre_done[1] = ev[2]; v->list_free[0] = ev[3]; v->list_free[1] = ev[4]; v->seq_ready = ev[5];
-        v->pre_stream = ps;
-        v->rb_stream = rbs;
     }
     // this launch's parity: its counter block, its half of the work list, its table slot
     // (slabs too large to be pipelined -- see pipeline_ok -- keep one list and one parity)
@@ -771,6 +753,24 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
 #ifdef TSDF_EXPERIMENTS
     if (!shipped_variant(v->variant) || std::getenv("TSDF_NO_PIPELINE")) pipelined = false;   // the measurement build's own kernels run on the handle's stream
 #endif
+    if (pipelined && !v->pre_stream) {
+        // the two side streams of a pipelined handle, at its first pipelined launch (a stream costs about 2 MiB of device memory:
+        // the per-object handles of a scene, which are fed frame by frame and never pipeline, do not pay for them)
+        hipStream_t a = nullptr, b = nullptr;
+        int prio = 0;
+#ifdef TSDF_EXPERIMENTS
+        if (std::getenv("TSDF_PRE_PRIORITY")) { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); prio = hi; }   // (numerically lower = higher)
+#endif
+        // (default priority: with the highest one the pre-pass finished 180 us into the launch beside it, which then ran 65 us longer)
+        hipError_t e = hipStreamCreateWithPriority(&a, hipStreamNonBlocking, prio);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&b, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            if (a) (void)hipStreamDestroy(a);
+            return fail(TSDF_ERR_HIP, "side streams: %s", hipGetErrorString(e));
+        }
+        v->pre_stream = a;
+        v->rb_stream = b;
+    }
     const hipStream_t ps = pipelined ? v->pre_stream : v->stream;
     if (pipelined) {
         HIP_TRY(hipStreamWaitEvent(ps, inputs_ready, 0));
@@ -837,7 +837,7 @@ int launch_multi(tsdf_volume *v, const float *const *depth_dev, const uint8_t *c
         if (total > 0x7fffffffll - 1024) return fail(TSDF_ERR_INVALID, "fused launch: %lld bricks exceed the work list's 32-bit index", (long long)total);
         if (v->work_entries < (size_t)total) {
             if (v->d_work) {      // (a list in flight on either stream is done before its memory goes)
-                HIP_TRY(hipStreamSynchronize(v->pre_stream));
+                if (v->pre_stream) HIP_TRY(hipStreamSynchronize(v->pre_stream));
                 HIP_TRY(hipStreamSynchronize(v->stream));
                 HIP_TRY(hipFree(v->d_work));
             }
@@ -948,7 +948,7 @@ int integrate_frames(tsdf_volume *v, const float *const *depth_dev, const uint8_
         const int n = fuse ? std::min(frames_per_launch(v), n_frames - k) : 1;
         float c2b[16 * tsdfk::kMaxFramesPerLaunch];
         for (int i = 0; i < n; ++i) compose_cam2base(v, cam2world + 16 * (k + i), c2b + 16 * i);
-        if (fuse && !seq_event && v->seq_ready && n_frames > n) {
+        if (fuse && !seq_event && v->seq_ready && v->pipeline_ok && n_frames > n) {
             HIP_TRY(hipEventRecord(v->seq_ready, v->stream));
             seq_event = true;
         }
@@ -1580,7 +1580,7 @@ int tsdf_integrate_frames_labels_device(tsdf_volume *v, const float *const *dept
         const int n = std::min(frames_per_launch(v), n_frames - k);
         float c2b[16 * tsdfk::kMaxFramesPerLaunch];
         for (int i = 0; i < n; ++i) compose_cam2base(v, cam2world + 16 * (k + i), c2b + 16 * i);
-        if (!seq_event && v->seq_ready && n_frames > n) {
+        if (!seq_event && v->seq_ready && v->pipeline_ok && n_frames > n) {
             HIP_TRY(hipEventRecord(v->seq_ready, v->stream));
             seq_event = true;
         }

@@ -55,6 +55,10 @@ print('S-surf 512^3, list_bucket mode $m: %.5f ms per frame, measured traffic %.
       echo "fine tiles $m | $w: $(TSDF_HIP_LIB=$PWD/semantic_slam_amd/libtsdf_hip_exp.so TSDF_FINE_TILES=$m python3 bench.py $w --no-extras --no-traffic --no-cpu-baseline 2>> $out/_bench.err | python3 -c "import sys, json; d = json.loads(sys.stdin.read().strip()); print(d['ms_per_step'], 'ms per frame,', d['value'], 'Mvox/s')")"
     done; done
     for m in 0 1; do echo "fine tiles $m:"; TSDF_HIP_LIB=$PWD/semantic_slam_amd/libtsdf_hip_exp.so TSDF_FINE_TILES=$m python3 tools/claim_rate.py --workload ssurf --shapes 2,4,8 2>/dev/null | tail -2; done ) > $out/${R}_fine_tiles.txt 2>&1
+  # sequence calls with the pre-pass on the handle's stream / beside the previous launch (TSDF_PIPELINE forces it off / on for every slab size)
+  ( for rep in 1 2; do for w in "--workload ssurf --grid 200" "--workload ssurf --grid 320" "--workload ssurf" "--workload traj"; do for m in 0 1; do
+      echo "pipelined $m | $w: $(TSDF_HIP_LIB=$PWD/semantic_slam_amd/libtsdf_hip_exp.so TSDF_PIPELINE=$m python3 bench.py $w --no-extras --no-traffic --no-cpu-baseline 2>> $out/_bench.err | python3 -c "import sys, json; d = json.loads(sys.stdin.read().strip()); print(d['ms_per_step'], 'ms per frame,', d['value'], 'Mvox/s')")"
+    done; done; done ) > $out/${R}_pipeline.txt 2>&1
   # the caller's frame into the pinned ring: memcpy against streaming stores, same box, the reference's call shape
   ( echo "memcpy:"; TSDF_HIP_LIB=$PWD/semantic_slam_amd/libtsdf_hip_exp.so TSDF_PLAIN_MEMCPY=1 python3 tools/host_path_time.py 2>/dev/null | head -1
     echo "streaming stores (what ships):"; TSDF_HIP_LIB=$PWD/semantic_slam_amd/libtsdf_hip_exp.so python3 tools/host_path_time.py 2>/dev/null | head -1
