@@ -546,38 +546,11 @@ __device__ __forceinline__ void class_pose_store(ClassPoseTable *t, const int f,
 // fine: the frame's fine table (fine_tile_levels) or null; consulted when the box spans at most 7 x 7 fine tiles, i.e. when the
 // four overlapping blocks of a level it holds cover the box -- the tiles then hug the box more closely than the coarse ones and
 // the same comparisons decide more often; any table of correct tile bounds gives a correct claim.
-// SPHERE (the pre-pass only, PAIRED): before any corner is projected, the box's enclosing sphere is tested against the four side
-// planes of the frame's view, each pushed outwards by the pixel margin; when EVERY lane's frame has the whole sphere outside one of
-// them (and in front of the camera, beyond cz_short) the wavefront returns "skipped" at once -- 60 % of the super-bricks of a large
-// volume lie outside all 32 views of a launch, and the pre-pass is bound by its instructions (~300 per wavefront; this test: ~40).
-// It claims nothing the corner test would not: a sphere that contains the box and lies beyond the plane u = -margin (etc.) has all
-// eight corners there too, and the radius is padded by 0.1 % + 1 mm, far more than the rounding of this arithmetic (1e-6 relative).
-template <bool PAIRED = false, bool SPHERE = false>
+template <bool PAIRED = false>
 __device__ __forceinline__ int classify_patch(const IntegrateParams &p, const ClassPose &q, const int xa,
                                               const int xb, const int ya, const int yb, const int gz, const int gz1 = -1,
                                               const float2 *__restrict__ fine = nullptr)
 {
-    static_assert(!SPHERE || PAIRED, "the sphere test exits for the whole wavefront");
-    if constexpr (SPHERE) {
-        const int zb = gz1 > gz ? gz1 : gz;
-        const float hx = 0.5f * (float)(xb - xa) * p.vs, hy = 0.5f * (float)(yb - ya) * p.vs, hz = 0.5f * (float)(zb - gz) * p.vs;
-        const float r = sqrtf(hx * hx + hy * hy + hz * hz) * 1.001f + 1.0e-3f;
-        const float dx = (p.ox + 0.5f * (float)(xa + xb) * p.vs) - q.tx, dy = (p.oy + 0.5f * (float)(ya + yb) * p.vs) - q.ty,
-                    dz = (p.oz + 0.5f * (float)(gz + zb) * p.vs) - q.tz;
-        const float cx = q.rx0 * dx + q.rx1 * dy + q.rx2 * dz;
-        const float cy = q.ry0 * dx + q.ry1 * dy + q.ry2 * dz;
-        const float cz = q.rz0 * dx + q.rz1 * dy + q.rz2 * dz;
-        // side planes through the camera centre: u = -mu  <=>  fx x + (cx0 + mu) z = 0, u = W - 1 + mu  <=>  fx x - (W - 1 + mu - cx0) z = 0, ...
-        const float al = p.cx + p.px_margin_u, ar = ((float)(p.W - 1) + p.px_margin_u) - p.cx;
-        const float at = p.cy + p.px_margin_v, ab = ((float)(p.H - 1) + p.px_margin_v) - p.cy;
-        const float left = p.fx * cx + al * cz, right = p.fx * cx - ar * cz;      // < 0 beyond the left plane, > 0 beyond the right one
-        const float top = p.fy * cy + at * cz, bottom = p.fy * cy - ab * cz;
-        const float nl = sqrtf(p.fx * p.fx + al * al) * r, nr = sqrtf(p.fx * p.fx + ar * ar) * r;
-        const float nt = sqrtf(p.fy * p.fy + at * at) * r, nb = sqrtf(p.fy * p.fy + ab * ab) * r;
-        const bool outside = (left < -nl) | (right > nr) | (top < -nt) | (bottom > nb);
-        const bool gone = outside & (cz - r > q.cz_short) & (cz + r < 3.0e38f) & (q.tiles != nullptr);   // (comparisons with a NaN are false: no claim)
-        if (__ballot(!gone) == 0ull) return 2;
-    }
     if constexpr (!PAIRED) { if (q.tiles == nullptr) return 0; }
     const float dxa = (p.ox + (float)xa * p.vs) - q.tx, dxb = (p.ox + (float)xb * p.vs) - q.tx;
     const float dya = (p.oy + (float)ya * p.vs) - q.ty, dyb = (p.oy + (float)yb * p.vs) - q.ty;
@@ -1317,7 +1290,7 @@ __global__ __launch_bounds__(256) void classify_brick_list(MultiParamsInline mp,
     // the frames as integrate_brick_list's self-classifying wavefronts read them (the first wavefront of the launch writes)
     if (id == 0 && lane < kMaxFramesPerLaunch) class_pose_store(bl.poses, lane, mine_q);
     const float2 *fine_f = p.fine != nullptr ? p.fine + (size_t)(lane & 31) * fine_table_elems(p.fine_w, p.fine_h) : nullptr;
-    const int cls = classify_patch<true, true>(p, mine_q, xa, xb, ya, yb, p.z_begin + z0, p.z_begin + z1, fine_f);
+    const int cls = classify_patch<true>(p, mine_q, xa, xb, ya, yb, p.z_begin + z0, p.z_begin + z1, fine_f);
     const unsigned int super_free = (unsigned int)__ballot(cls == 1) & frames_mask;
     const unsigned int super_skip = (unsigned int)__ballot(cls == 2) & frames_mask;
     const int n_in = (i1 - i0 + 1) * (g1 - g0 + 1) * (zg1 - zg0 + 1);
