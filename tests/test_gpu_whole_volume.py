@@ -122,6 +122,22 @@ def test_config3_one_ranks_slab_of_the_1024_cube(cuda, oracle, path):
         wv.drop(f"fr3_1024_{n}")
 
 
+@pytest.mark.parametrize("rank_,path", [(0, "fused"), (7, "fused_bricks"), (5, "fused")])
+def test_config3_other_ranks_slabs_of_the_1024_cube(cuda, oracle, rank_, path):
+    """The same for the slabs at the two ends of the grid (rank 0: z_begin = 0, the slices nearest the first keyframe's camera;
+    rank 7: the last slices, z_end = dim_z) and one more in the middle: every voxel against the same slices of the reference
+    kernel's full-grid replay of all 194 keyframes."""
+    T = wv.fr3_trajectory(oracle, cuda)
+    n = T["n"]
+    ref_t, ref_w = wv.fr3_reference(cuda, oracle, n)
+    c, dims = T["cfg"], T["dims"]
+    zb, ze = rank_ * dims[2] // 8, (rank_ + 1) * dims[2] // 8
+    cfg = capi.make_config(dims, c.voxel_size, list(c.origin), base2world=list(c.base2world), z_begin=zb, z_end=ze)
+    with capi.Volume(cfg) as vol:
+        _run_path(vol, path, T["poses"][:n], T["dev"][:n], T["depths"][:n])
+        wv.assert_volume_equals_reference(cuda, f"slab [{zb}, {ze}) of 1024^3 / {path}", vol, ref_t, ref_w, dims)
+
+
 # ---- (d) the reference's own usage: one 200^3 volume per object instance ----------------------------------------------
 @pytest.mark.parametrize("path", ["batch_deferred", "batch_per_frame", "handles"])
 def test_sixteen_masked_object_volumes_every_voxel_equals_the_reference_kernel(cuda, oracle, path):
