@@ -208,14 +208,17 @@ def test_512_cube_as_a_group_of_slabs_every_voxel_equals_the_reference_kernel(cu
 
 
 # ---- 8-pixel depth tiles with an image that is no multiple of anything ---------------------------------------------
+@pytest.mark.parametrize("nz", [96, 512])      # 12.6 M voxels: 8-pixel tiles; 67 M: the 4-pixel fine tables beside them
 @pytest.mark.parametrize("hw", [(333, 517), (250, 402)])
-def test_fine_tiles_with_odd_image_sizes_every_voxel_equals_the_reference_kernel(cuda, oracle, hw):
+def test_fine_tiles_with_odd_image_sizes_every_voxel_equals_the_reference_kernel(cuda, oracle, hw, nz):
     """Slabs of 10 M voxels and more classify against 8 x 8-pixel depth tiles.  The other whole-volume tests use 640 x 480
     images (80 x 60 whole tiles); here the image is 517 x 333 / 402 x 250 pixels -- partial tiles on both borders, rows
     that are no multiple of four pixels (the table kernel's scalar path) -- with intrinsics to match, through sensor noise and
-    dropouts, 24 frames fused over the brick work list: every voxel of the 512 x 256 x 96 grid against the reference kernel."""
+    dropouts, 24 frames fused over the brick work list: every voxel of the 512 x 256 x 96 grid against the reference kernel --
+    and of a 512 x 256 x 512 grid, large enough for the fine tables (129 x 84 / 101 x 63 tiles of 4 pixels, partial on both
+    borders, their level (0, 0) written by the strip kernel's scalar path)."""
     h, w = hw
-    dims, vs = (512, 256, 96), 0.004
+    dims, vs = (512, 256, nz), 0.004
     K = np.array([0.83 * w, 0, 0.49 * w, 0, 0.84 * w, 0.52 * h, 0, 0, 1], np.float32)
     origin = np.array([-dims[0] * vs / 2, -dims[1] * vs / 2, 1.1], np.float32)
     cfg = capi.make_config(dims, vs, origin, K=K, im_height=h, im_width=w)
@@ -223,7 +226,7 @@ def test_fine_tiles_with_odd_image_sizes_every_voxel_equals_the_reference_kernel
     poses = np.stack([scene.pose(k, 24) for k in range(24)])
     depths = synth.sensor_imperfections([scene.depth(p, quantize=True) for p in poses], 2.0, 0.05)
     dev = [cuda.from_numpy(d).cuda() for d in depths]
-    ref_t, ref_w = wv.replay(cuda, f"odd{h}x{w}", cfg.cam_K, dims, cfg.origin, cfg.voxel_size, cfg.trunc_margin, poses, dev)
+    ref_t, ref_w = wv.replay(cuda, f"odd{h}x{w}x{nz}", cfg.cam_K, dims, cfg.origin, cfg.voxel_size, cfg.trunc_margin, poses, dev)
     frac = float((ref_w > 0).sum()) / ref_w.numel()
     assert 0.05 < frac < 0.98, frac
     for variant in (8, 0):
@@ -231,6 +234,6 @@ def test_fine_tiles_with_odd_image_sizes_every_voxel_equals_the_reference_kernel
             vol.set_kernel_variant(variant)
             vol.integrate_frames_device([d.data_ptr() for d in dev], poses)
             info = vol.classification_info()
-            wv.assert_volume_equals_reference(cuda, f"{w} x {h} image, 8-pixel tiles, variant {variant}", vol, ref_t, ref_w, dims)
+            wv.assert_volume_equals_reference(cuda, f"{w} x {h} image, nz {nz}, variant {variant}", vol, ref_t, ref_w, dims)
         assert info[0] > 0.3, info
-    wv.drop(f"odd{h}x{w}")
+    wv.drop(f"odd{h}x{w}x{nz}")
