@@ -30,6 +30,12 @@ done
 # the N > 1 line on the one GPU there is: one rank's slab of configs[3] (1024^3 @ 2 mm cut eight ways), and the whole N-rank code
 # path over RCCL with one rank (process group, fences, strong_512 / n1_same_job legs, halo step, extraction)
 python3 bench.py --emulate-world 8 --emulate-rank 3 --steps 20 --warmup 5 --no-cpu-baseline > $out/${R}_bench_configs3_rank3_of_8.json 2>> $out/_bench.err || exit 1
+# north_star's 512^3 strong scaling slab by slab, and the driver's N = 2 command at full size over gloo (both ranks on this GPU)
+( echo "# bench.py --emulate-world N --emulate-rank r --grid 512: ms per step, Mvox/s of the slab, roofline.frac"
+  for wr in "8 0" "8 5" "4 0" "2 1"; do set -- $wr
+    echo "N = $1, rank $2: $(python3 bench.py --emulate-world $1 --emulate-rank $2 --grid 512 --steps 20 --warmup 5 --no-extras --no-traffic --no-cpu-baseline 2>> $out/_bench.err | python3 -c "import sys, json; d = json.loads(sys.stdin.read().strip()); print(d['ms_per_step'], d['value'], d['roofline']['frac'])")"
+  done ) > $out/${R}_strong512_rank_slabs.txt
+TSDF_BENCH_BACKEND=gloo python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 20 --warmup 5 2>> $out/_bench.err | grep "^{" > $out/${R}_bench_2rank_gloo_rehearsal.json
 python3 bench.py --dist-world1 --steps 20 --warmup 5 --no-extras --strong-leg --no-traffic --no-cpu-baseline 2>> $out/_bench.err | grep "^{" > $out/${R}_bench_dist_world1_rccl.json || exit 1     # (RCCL prints a version banner on stdout first)
 # SQ counters of the Integrate kernel of the classified fused launches and of the per-voxel fused kernel in the band
 for t in "ssurf512 --workload ssurf" "traj1024 --workload traj" "sband512_fused --workload sband --mode fused"; do
