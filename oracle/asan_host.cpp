@@ -1,12 +1,13 @@
 // asan_host.cpp -- the product's HOST-side arithmetic (no device code) compiled for the CPU sanitizer run:
 // semantic_slam_amd/csrc/pose_math.h (4x4 multiply / cofactor inverse, ref: src/tsdf.cu:253-403) and
-// semantic_slam_amd/csrc/host_derive.h (wavefront brick choice, guards and margins of the exact shortcuts), behind plain C
-// entry points, linked with tsdf_oracle.c into oracle/_asan/liboracle_asan.so by `make -C oracle asan`
+// semantic_slam_amd/csrc/host_derive.h (wavefront brick choice, guards and margins of the exact shortcuts) and
+// semantic_slam_amd/csrc/host_copy.h (the caller's frame into the pinned ring: streaming stores), behind plain C entry points, linked with tsdf_oracle.c into oracle/_asan/liboracle_asan.so by `make -C oracle asan`
 // (-fsanitize=address,undefined -fno-sanitize-recover=all).  tests/test_sanitizers.py runs the golden vectors, the pose
 // known-answer tests, the writers and these entry points under it.  TEST INFRASTRUCTURE: the headers are
 // the product's own files, compiled here a second time; nothing in the product loads this library.
 #include "../semantic_slam_amd/csrc/host_derive.h"
 #include "../semantic_slam_amd/csrc/pose_math.h"
+#include "../semantic_slam_amd/csrc/host_copy.h"
 
 extern "C" {
 
@@ -30,5 +31,8 @@ void asan_projection_guards(const tsdf_config *c, const float *cam2base, float o
     out[0] = g.cz_margin; out[1] = (float)g.fast_ok; out[2] = (float)g.trunc_fast;
     out[3] = g.cz_short; out[4] = g.cz_pad; out[5] = g.px_margin_u; out[6] = g.px_margin_v;
 }
+
+// dst / src: any alignment, any size (the product hands it page-aligned ring slots and whole frames)
+void asan_copy_to_pinned(void *dst, const void *src, size_t n) { tsdf_host::copy_to_pinned(dst, src, n); }
 
 }  // extern "C"

@@ -138,6 +138,18 @@ def main():
             if not np.all(np.isfinite(pose)):
                 ok(g[1] == 0.0 and g[0] >= 3.0e38 and g[3] >= 3.0e38, "a pose that is not finite must switch every shortcut off")
 
+    # ---- the caller's frame into the pinned ring (csrc/host_copy.h: 32-byte streaming stores from 64 KiB, memcpy below) ---------------
+    L.asan_copy_to_pinned.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    src = rng.integers(0, 256, 1228800 + 300).astype(np.uint8)
+    for n_bytes in (0, 1, 31, 65535, 65536, 65537, 65536 + 127, 65536 + 128, 65536 + 129, 614400, 1228800):
+        for s_off in (0, 1, 13, 32):
+            for d_off in (0, 1, 31, 32, 64):
+                dst = np.full(n_bytes + d_off + 96, 0xA5, np.uint8)          # exact-size heap blocks: an over-read or over-write is ASan's to find
+                part = np.ascontiguousarray(src[s_off:s_off + n_bytes])
+                L.asan_copy_to_pinned(dst.ctypes.data + d_off, part.ctypes.data, n_bytes)
+                ok(np.array_equal(dst[d_off:d_off + n_bytes], part) and np.all(dst[:d_off] == 0xA5) and np.all(dst[d_off + n_bytes:] == 0xA5),
+                   (n_bytes, s_off, d_off))
+
     # ---- writers and extraction (tests/test_writers_and_adapters.py, tests/test_oracle_extras.py) --------------------------------
     g = Golden(NAMES[1])
     t, w = orc.init_grid(g.dims)
