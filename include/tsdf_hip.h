@@ -129,6 +129,11 @@ int tsdf_integrate_cam2base(tsdf_volume *vol, const float *depth_dev, const floa
  * several frames per pass over the volume (weights read and written once per group).
  * depth_dev: n_frames device pointers; masks_dev: NULL or n_frames device pointers (entries may be
  * NULL); cam2world: n_frames x 16 floats.
+ * Ordering: every frame (and mask) must be readable once the work queued on the handle's stream before this call has
+ * run, and must stay unchanged until the work queued by this call has run.  On slabs below 64 M voxels the library
+ * reads the frames of a later pass (their depth tile tables, the brick work list) on a side stream of its own while an
+ * earlier pass is still integrating; that stream waits for an event recorded on the handle's stream when the call starts
+ * and is joined to the handle's stream before the call returns, so the caller sees one stream as before.
  */
 int tsdf_integrate_frames_device(tsdf_volume *vol, const float *const *depth_dev, const uint8_t *const *masks_dev,
                                  const float *cam2world, int32_t n_frames);
@@ -205,6 +210,8 @@ int tsdf_last_cam2base(const tsdf_volume *vol, float out[16]);
 /*
  * Run subsequent work of this handle on a caller-owned hipStream_t (passed as void*), e.g.
  * the current PyTorch stream, or back on the handle's own stream when stream == NULL.
+ * (Copies of host frames run on the store's copy stream and, for sequence calls, table kernels on a side stream of the
+ * handle; both are ordered against this stream by events, so work queued on it after a call sees that call's result.)
  */
 int tsdf_set_stream(tsdf_volume *vol, void *hip_stream);
 int tsdf_get_stream(tsdf_volume *vol, void **hip_stream);
