@@ -226,14 +226,17 @@ def test_wide_slices_fall_back_to_memory_order(cuda, oracle):
     assert ref_w.max() == 3 and ref_w.min() < 3
 
 
+@pytest.mark.parametrize("caller_stream", [False, True])
 @pytest.mark.parametrize("variant", [8, 0])
-def test_pipelined_sequence_calls_keep_call_order(cuda, oracle, variant):
+def test_pipelined_sequence_calls_keep_call_order(cuda, oracle, variant, caller_stream):
     """A sequence call on a slab below 64 M voxels runs the pre-pass of launch k + 1 (depth tile tables, the brick work list) on a
     side stream beside launch k's Integrate kernel, with two work lists, two counter blocks and two table slots in turn
     (csrc/tsdf_capi.hip, launch_multi).  Many launches per call (7, then 3, then 5: the parity of the buffers changes between
     calls), a different depth frame for every pose, frames that update nothing in between, and calls of other kinds wedged between
     the sequence calls -- one frame through its own launch, a download, a host-pointer frame that is collected and flushed by the
-    next call: the result must be the oracle's for the same frames in call order, bit for bit."""
+    next call: the result must be the oracle's for the same frames in call order, bit for bit.  caller_stream: the handle runs on a
+    stream the caller owns (tsdf_set_stream), the frames are uploaded on that stream right before each call (no synchronisation
+    in between: the side stream must wait for what precedes the call on the caller's stream)."""
     dims, vs = (200, 96, 64), 0.01
     origin = synth.surf_volume(200, vs, 0.7)
     cfg = capi.make_config(dims, vs, origin)
@@ -251,18 +254,29 @@ def test_pipelined_sequence_calls_keep_call_order(cuda, oracle, variant):
 
     keep = []
 
+    stream = cuda.cuda.Stream() if caller_stream else None
+
     def sequence(vol, fr):
-        dev = [cuda.from_numpy(d).cuda() for _, d in fr]
+        if stream is None:
+            dev = [cuda.from_numpy(d).cuda() for _, d in fr]
+        else:
+            with cuda.cuda.stream(stream):      # uploads queued on the caller's stream, not waited for
+                pinned = [cuda.from_numpy(d).pin_memory() for _, d in fr]
+                dev = [t.to("cuda", non_blocking=True) for t in pinned]
+            keep.append(pinned)
         keep.append(dev)
         vol.integrate_frames_device([d.data_ptr() for d in dev], np.stack([p for p, _ in fr]))
 
     with capi.Volume(cfg) as vol:
+        if stream is not None:
+            vol.set_stream(stream.cuda_stream)
         vol.set_kernel_variant(variant)
         a = [frame(k) for k in range(0, 7 * 32 - 5)]
         sequence(vol, a)
         oracle_apply(a)
         one = frame(500)
         d_one = cuda.from_numpy(one[1]).cuda()
+        cuda.cuda.synchronize()
         vol.set_deferral(0)
         vol.integrate_device(d_one.data_ptr(), one[0])                  # its own launch on the handle's stream
         oracle_apply([one])
